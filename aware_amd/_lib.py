@@ -1,0 +1,123 @@
+"""ctypes binding of libaware_hip.so (the C ABI declared in include/aware_hip.h).
+
+The shared library is built in-tree by `build_library()` (called from
+__graft_entry__.build()).  There is no CPU fallback: every compute entry point of this
+package goes through this library and raises if it is missing or if no GPU is present.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaware_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+SOURCES = ["capi.hip", "dsp_kernels.hip", "detector_kernels.hip", "attack_kernels.hip"]
+
+AWARE_OK = 0
+ERRORS = {-1: "bad argument", -2: "unsupported configuration", -3: "HIP runtime error", -4: "workspace too small"}
+
+
+class AwareHipError(RuntimeError):
+    pass
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 into aware_amd/libaware_hip.so (hipcc cross-compiles
+    without a GPU)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in ("common.hpp", "fft512.hpp", "kernels.h")] + [
+        os.path.join(_HERE, "..", "include", "aware_hip.h")]
+    if not force and os.path.exists(LIB_PATH):
+        t = os.path.getmtime(LIB_PATH)
+        if all(os.path.getmtime(d) <= t for d in deps):
+            return LIB_PATH
+    cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+class EmbedConfig(C.Structure):
+    _fields_ = [("num_iterations", C.c_int), ("tolerance_db", C.c_float), ("loss", C.c_int),
+                ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("momentum_decay", C.c_float), ("use_graph", C.c_int)]
+
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_pi = C.POINTER(C.c_int)
+
+# name -> (restype, argtypes); mirrors include/aware_hip.h one to one
+SIGNATURES = {
+    "aware_version": (_i, []),
+    "aware_last_hip_error": (C.c_char_p, []),
+    "aware_plan_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i, _i]),
+    "aware_plan_destroy": (None, [_vp]),
+    "aware_batch_create": (_i, [C.POINTER(_vp), _i, _pi, _pi]),
+    "aware_batch_destroy": (None, [_vp]),
+    "aware_batch_total_frames": (_i, [_vp]),
+    "aware_batch_total_pooled": (_i, [_vp]),
+    "aware_batch_total_out": (_i, [_vp]),
+    "aware_batch_out_offset": (_i, [_vp, _i]),
+    "aware_batch_out_length": (_i, [_vp, _i]),
+    "aware_batch_frames": (_i, [_vp, _i]),
+    "aware_batch_scratch_bytes": (_sz, [_vp]),
+    "aware_stft": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "aware_istft": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "aware_stft_band": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "aware_detector_create": (_i, [C.POINTER(_vp), _vp, _vp, _i, _i, _pi, C.POINTER(_vp), C.POINTER(_vp)]),
+    "aware_detector_destroy": (None, [_vp]),
+    "aware_detect_workspace_bytes": (_sz, [_vp, _vp]),
+    "aware_detect": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "aware_detector_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "aware_embed_workspace_bytes": (_sz, [_vp, _vp]),
+    "aware_embed_create": (_i, [C.POINTER(_vp), _vp, _vp, _vp, C.POINTER(EmbedConfig), _vp, _sz, _vp]),
+    "aware_embed_destroy": (None, [_vp]),
+    "aware_embed_begin": (_i, [_vp, _vp, _vp, _vp]),
+    "aware_embed_iterate": (_i, [_vp, _i, _vp]),
+    "aware_embed_gradient": (_i, [_vp, _vp, _vp]),
+    "aware_embed_finish": (_i, [_vp, _vp, _vp, _vp]),
+    "aware_embed_buffer": (_vp, [_vp, _i]),
+    "aware_pcm_quantize": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "aware_upfirdn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp]),
+    "aware_iir": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "aware_segment_cut": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "aware_gaussian_noise": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _f, _vp, _vp]),
+    "aware_gemm_nt": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
+}
+
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree library and attach the prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AwareHipError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  aware_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != AWARE_OK:
+        lib = load_library()
+        detail = lib.aware_last_hip_error().decode() if rc == -3 else ""
+        raise AwareHipError(f"{what}: {ERRORS.get(rc, rc)} {detail}".strip())
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise AwareHipError("aware_amd needs an MI355X (gfx950) GPU: torch.cuda.is_available() is False "
+                            "and there is no CPU fallback")

@@ -1,0 +1,218 @@
+// Attack-stage kernels (between embed and detect) for gfx950.
+//
+// Reference: /root/reference/scripts/attacks.py
+//   PCMBitDepthConversion.apply :44-70      -> pcm_quantize_kernel
+//   Resample.apply :267-294 (scipy.signal.resample_poly = upfirdn with a Kaiser FIR)
+//                                            -> upfirdn_kernel (also the 44.1k -> 16k front end,
+//                                               scripts/test.py:60-63)
+//   LowPassFilter / HighPassFilter :400-455 (scipy lfilter, float64, zero state)
+//   RandomBandstop :324-356 (scipy filtfilt, odd padding, lfilter_zi) -> iir_kernel
+//   DeleteSamples :162-178, Cropout :192-205, SampleSupression :370-385 -> segment_copy_kernel
+// Extension (not in the reference, BASELINE.json north_star): additive Gaussian noise
+// with a counter-based Philox generator, specified in oracle/aware_oracle.py.
+#include "common.hpp"
+#include "kernels.h"
+
+namespace aware {
+
+__global__ __launch_bounds__(256) void pcm_quantize_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                            const int* __restrict__ off, const int* __restrict__ len,
+                                                            const unsigned long long* __restrict__ pmax,
+                                                            const int* __restrict__ pcount, int pstride, float q,
+                                                            float lo, float hi) {
+    __shared__ unsigned long long red[4];
+    const int b = blockIdx.y;
+    ClipNorm cn = clip_norm_from_partials(pmax + (size_t)b * pstride, pcount[b], red);
+    const int n = len[b];
+    const float* x = in + off[b];
+    float* y = out + off[b];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float v = x[i] / cn.m;                 // audio / max(|audio| + 1e-8)
+        v = v * q;
+        v = fminf(fmaxf(v, lo), hi);           // np.clip
+        v = truncf(v);                         // astype(int): toward zero
+        y[i] = v / q;
+    }
+}
+
+// y[j] = sum_i x[i] * h[j*down - i*up + half_len], float32, x ascending (scipy upfirdn order)
+__global__ __launch_bounds__(256) void upfirdn_kernel(const float* __restrict__ in, const int* __restrict__ in_off,
+                                                       const int* __restrict__ in_len, float* __restrict__ out,
+                                                       const int* __restrict__ out_off, const int* __restrict__ out_len,
+                                                       const float* __restrict__ h, int nh, int up, int down,
+                                                       int half_len) {
+    const int b = blockIdx.y;
+    const int n_in = in_len[b], n_out = out_len[b];
+    const float* x = in + in_off[b];
+    float* y = out + out_off[b];
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n_out; j += gridDim.x * blockDim.x) {
+        const long pos = (long)j * down + half_len;
+        int i_hi = (int)(pos / up);
+        long tap = pos - (long)i_hi * up;               // tap index for i = i_hi
+        int i_lo = i_hi - (int)((nh - 1 - tap) / up);
+        if (i_lo < 0) i_lo = 0;
+        if (i_hi > n_in - 1) i_hi = n_in - 1;
+        float acc = 0.f;
+        for (int i = i_lo; i <= i_hi; ++i) acc += x[i] * h[pos - (long)i * up];
+        y[j] = acc;
+    }
+}
+
+// Direct-form-II-transposed IIR in float64, one thread per clip (the recurrence is
+// sequential in time; clips are the parallel dimension).  mode 0: lfilter with zero
+// state.  mode 1: filtfilt (odd extension by 3*ncoef samples, steady-state initial
+// conditions zi*x0, forward then backward); needs scratch[B][maxlen + 6*ncoef] doubles.
+constexpr int kMaxCoef = 12;
+__global__ __launch_bounds__(64) void iir_kernel(const float* __restrict__ in, const int* __restrict__ off,
+                                                  const int* __restrict__ len, void* __restrict__ outv, int out_f64,
+                                                  const double* __restrict__ bc, const double* __restrict__ ac,
+                                                  const double* __restrict__ zic, int ncoef, int mode,
+                                                  double* __restrict__ scratch, int sstride, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double bb[kMaxCoef], aa[kMaxCoef], z[kMaxCoef];
+    for (int k = 0; k < kMaxCoef; ++k) {
+        bb[k] = k < ncoef ? bc[(size_t)b * ncoef + k] : 0.0;
+        aa[k] = k < ncoef ? ac[(size_t)b * ncoef + k] : 0.0;
+        z[k] = 0.0;
+    }
+    const int n = len[b];
+    const float* x = in + off[b];
+    double* od = reinterpret_cast<double*>(outv) + off[b];
+    float* of = reinterpret_cast<float*>(outv) + off[b];
+    const int ns = ncoef - 1;
+    auto step = [&](double xi) {
+        double yi = bb[0] * xi + z[0];
+        for (int k = 0; k < ns - 1; ++k) z[k] = z[k + 1] + bb[k + 1] * xi - aa[k + 1] * yi;
+        z[ns - 1] = bb[ns] * xi - aa[ns] * yi;
+        return yi;
+    };
+    if (mode == 0) {
+        for (int i = 0; i < n; ++i) {
+            double yi = step((double)x[i]);
+            if (out_f64) od[i] = yi; else of[i] = (float)yi;
+        }
+        return;
+    }
+    const int edge = 3 * ncoef;
+    double* s = scratch + (size_t)b * sstride;
+    const int ne = n + 2 * edge;
+    // odd extension
+    const double x0 = (double)x[0], xl = (double)x[n - 1];
+    for (int i = 0; i < edge; ++i) s[i] = 2.0 * x0 - (double)x[edge - i];
+    for (int i = 0; i < n; ++i) s[edge + i] = (double)x[i];
+    for (int i = 0; i < edge; ++i) s[edge + n + i] = 2.0 * xl - (double)x[n - 2 - i];
+    // forward
+    for (int k = 0; k < ns; ++k) z[k] = zic[(size_t)b * ns + k] * s[0];
+    for (int i = 0; i < ne; ++i) s[i] = step(s[i]);
+    // backward
+    const double y0 = s[ne - 1];
+    for (int k = 0; k < ns; ++k) z[k] = zic[(size_t)b * ns + k] * y0;
+    for (int i = ne - 1; i >= 0; --i) s[i] = step(s[i]);
+    for (int i = 0; i < n; ++i) {
+        if (out_f64) od[i] = s[edge + i]; else of[i] = (float)s[edge + i];
+    }
+}
+
+// ---- EXTENSION: Gaussian noise at a target SNR (Philox-4x32-10 + Box-Muller) -------------
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0,
+                                              unsigned k1, unsigned (&r)[4]) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0, hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
+        unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    r[0] = c0; r[1] = c1; r[2] = c2; r[3] = c3;
+}
+
+__global__ __launch_bounds__(256) void power_kernel(const float* __restrict__ in, const int* __restrict__ off,
+                                                     const int* __restrict__ len, double* __restrict__ power) {
+    __shared__ double red[4];
+    const int b = blockIdx.x;
+    const int n = len[b];
+    const float* x = in + off[b];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += (double)x[i] * (double)x[i];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) power[b] = (red[0] + red[1] + red[2] + red[3]) / (double)n;
+}
+
+__global__ __launch_bounds__(256) void gaussian_noise_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                              const int* __restrict__ off, const int* __restrict__ len,
+                                                              const unsigned* __restrict__ seeds,
+                                                              const double* __restrict__ power, float snr_db) {
+    const int b = blockIdx.y;
+    const int n = len[b];
+    const float* x = in + off[b];
+    float* y = out + off[b];
+    const double sigma = sqrt(power[b] / pow(10.0, (double)snr_db / 10.0));
+    const int nblk = (n + 3) / 4;
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nblk; q += gridDim.x * blockDim.x) {
+        unsigned r[4];
+        philox4x32_10((unsigned)q, 0u, 0u, 0u, seeds[b], 0x5EEDu, r);
+        double u0 = ((double)r[0] + 0.5) / 4294967296.0, u1 = ((double)r[1] + 0.5) / 4294967296.0;
+        double u2 = ((double)r[2] + 0.5) / 4294967296.0, u3 = ((double)r[3] + 0.5) / 4294967296.0;
+        double ra = sqrt(-2.0 * log(u0)), rb = sqrt(-2.0 * log(u2));
+        double zz[4] = {ra * cos(two_pi * u1), ra * sin(two_pi * u1), rb * cos(two_pi * u3), rb * sin(two_pi * u3)};
+        for (int e = 0; e < 4; ++e) {
+            int i = 4 * q + e;
+            if (i < n) y[i] = (float)((double)x[i] + sigma * zz[e]);
+        }
+    }
+}
+
+// delete a span (out shorter than in) or zero it (same length)
+__global__ __launch_bounds__(256) void segment_copy_kernel(const float* __restrict__ in, const int* __restrict__ in_off,
+                                                            float* __restrict__ out, const int* __restrict__ out_off,
+                                                            const int* __restrict__ out_len,
+                                                            const int* __restrict__ cut_start,
+                                                            const int* __restrict__ cut_len, int zero_fill) {
+    const int b = blockIdx.y;
+    const int n = out_len[b], s0 = cut_start[b], k = cut_len[b];
+    const float* x = in + in_off[b];
+    float* y = out + out_off[b];
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        if (zero_fill) y[j] = (j >= s0 && j < s0 + k) ? 0.f : x[j];
+        else y[j] = (j < s0) ? x[j] : x[j + k];
+    }
+}
+
+static inline int gx(int max_len) { int g = (max_len + 1023) / 1024; return g < 1 ? 1 : g; }
+
+void launch_pcm_quantize(const float* in, float* out, const int* off, const int* len, const unsigned long long* pmax,
+                         const int* pcount, int pstride, float q, float lo, float hi, int B, int max_len,
+                         hipStream_t st) {
+    hipLaunchKernelGGL(pcm_quantize_kernel, dim3(gx(max_len), B), dim3(256), 0, st, in, out, off, len, pmax, pcount,
+                       pstride, q, lo, hi);
+}
+void launch_upfirdn(const float* in, const int* in_off, const int* in_len, float* out, const int* out_off,
+                    const int* out_len, const float* h, int nh, int up, int down, int half_len, int B, int max_out,
+                    hipStream_t st) {
+    hipLaunchKernelGGL(upfirdn_kernel, dim3(gx(max_out), B), dim3(256), 0, st, in, in_off, in_len, out, out_off, out_len,
+                       h, nh, up, down, half_len);
+}
+void launch_iir_full(const float* in, const int* off, const int* len, void* out, int out_f64, const double* b,
+                     const double* a, const double* zi, int ncoef, int mode, double* scratch, int sstride, int B,
+                     hipStream_t st) {
+    hipLaunchKernelGGL(iir_kernel, dim3((B + 63) / 64), dim3(64), 0, st, in, off, len, out, out_f64, b, a, zi, ncoef,
+                       mode, scratch, sstride, B);
+}
+void launch_gaussian_noise_full(const float* in, float* out, const int* off, const int* len, const unsigned* seeds,
+                                double* power, float snr_db, int B, int max_len, hipStream_t st) {
+    hipLaunchKernelGGL(power_kernel, dim3(B), dim3(256), 0, st, in, off, len, power);
+    hipLaunchKernelGGL(gaussian_noise_kernel, dim3(gx(max_len / 4 + 1), B), dim3(256), 0, st, in, out, off, len, seeds,
+                       power, snr_db);
+}
+void launch_segment_copy(const float* in, const int* in_off, float* out, const int* out_off, const int* out_len,
+                         const int* cut_start, const int* cut_len, int zero_fill, int B, int max_len, hipStream_t st) {
+    hipLaunchKernelGGL(segment_copy_kernel, dim3(gx(max_len), B), dim3(256), 0, st, in, in_off, out, out_off, out_len,
+                       cut_start, cut_len, zero_fill);
+}
+
+}  // namespace aware

@@ -1,0 +1,739 @@
+// extern "C" entry points of libaware_hip (see include/aware_hip.h for the contract and the
+// reference code each one replaces).  Host-side orchestration only: geometry tables,
+// workspace carving, launch sequences, optional hipGraph capture of one optimiser iteration.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/aware_hip.h"
+#include "common.hpp"
+#include "kernels.h"
+
+using namespace aware;
+
+static thread_local std::string g_last_err;
+
+#define HIPCHK(expr)                                                                  \
+    do {                                                                              \
+        hipError_t _e = (expr);                                                       \
+        if (_e != hipSuccess) {                                                       \
+            g_last_err = std::string(#expr) + ": " + hipGetErrorString(_e);           \
+            return AWARE_E_HIP;                                                       \
+        }                                                                             \
+    } while (0)
+#define LAUNCHCHK() HIPCHK(hipGetLastError())
+
+// ---------------------------------------------------------------------------------------------
+struct aware_plan {
+    PlanDev dev;
+    void* mem = nullptr;
+};
+
+struct aware_batch {
+    int B = 0;
+    std::vector<int> n, in_off, T, frame_off, pool_off, out_off, out_len, pc_in, pc_syn;
+    int NF = 0, NP = 0, NS = 0, max_frames = 0, max_len = 0, pstride = 0;
+    // device tables (one allocation)
+    int* d_mem = nullptr;
+    int *d_frame_off = nullptr, *d_pool_off = nullptr, *d_in_off = nullptr, *d_in_len = nullptr, *d_out_off = nullptr,
+        *d_out_len = nullptr, *d_pc_in = nullptr, *d_pc_syn = nullptr;
+};
+
+struct aware_detector {
+    int n_mels = 0, n_layers = 0, nbits = 0;
+    int ch[8] = {0};
+    int maxc = 0;
+    float* mem = nullptr;
+    float* melT = nullptr;   // [n_mels][256]  (Bt of the forward mel GEMM)
+    float* melB = nullptr;   // [256][n_mels]  (Bt of its data-gradient)
+    float* w[8] = {nullptr};   // [Cout][Cin]
+    float* wT[8] = {nullptr};  // [Cin][Cout]
+    float* bias[8] = {nullptr};
+};
+
+extern "C" int aware_version(void) { return 100; }
+extern "C" const char* aware_last_hip_error(void) { return g_last_err.c_str(); }
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int aware_plan_create(aware_plan** out, int n_fft, int hop, int win_length, int window, int band_lo_bin,
+                                 int band_hi_bin) {
+    if (!out) return AWARE_E_BADARG;
+    if (n_fft != kNfft || hop != kHop || win_length != kNfft) return AWARE_E_UNSUPPORTED;
+    if (window != 0 && window != 1) return AWARE_E_BADARG;
+    const int nband = band_hi_bin - band_lo_bin + 1;
+    if (band_lo_bin < 1 || band_hi_bin > 511 || nband < 1 || nband > kFS) return AWARE_E_UNSUPPORTED;
+    const double PI = 3.14159265358979323846;
+    std::vector<float> h(2 * 512 + 2 * 512 + 1024 + 1024);
+    float* tw512 = h.data();
+    float* tw1024 = tw512 + 1024;
+    float* win = tw1024 + 1024;
+    float* win2 = win + 1024;
+    for (int j = 0; j < 512; ++j) {
+        tw512[2 * j] = (float)cos(2 * PI * j / 512);
+        tw512[2 * j + 1] = (float)-sin(2 * PI * j / 512);
+        tw1024[2 * j] = (float)cos(2 * PI * j / 1024);
+        tw1024[2 * j + 1] = (float)-sin(2 * PI * j / 1024);
+    }
+    for (int i = 0; i < 1024; ++i) {
+        // torch.hann_window / torch.hamming_window (periodic), utils/audio/stft.py:19-25
+        double w = (window == 0) ? 0.5 - 0.5 * cos(2 * PI * i / 1024) : 0.54 - 0.46 * cos(2 * PI * i / 1024);
+        win[i] = (float)w;
+        win2[i] = win[i] * win[i];
+    }
+    aware_plan* p = new aware_plan();
+    HIPCHK(hipMalloc(&p->mem, h.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(p->mem, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    float* d = (float*)p->mem;
+    p->dev.tw512 = (const cf*)d;
+    p->dev.tw1024 = (const cf*)(d + 1024);
+    p->dev.window = d + 2048;
+    p->dev.window2 = d + 3072;
+    p->dev.band_lo = band_lo_bin;
+    p->dev.nband = nband;
+    *out = p;
+    return AWARE_OK;
+}
+extern "C" void aware_plan_destroy(aware_plan* p) {
+    if (!p) return;
+    if (p->mem) (void)hipFree(p->mem);
+    delete p;
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int aware_batch_create(aware_batch** out, int B, const int* n_samples, const int* in_offsets) {
+    if (!out || B < 1 || !n_samples) return AWARE_E_BADARG;
+    aware_batch* b = new aware_batch();
+    b->B = B;
+    b->n.assign(n_samples, n_samples + B);
+    b->in_off.resize(B);
+    b->T.resize(B);
+    b->frame_off.resize(B + 1);
+    b->pool_off.resize(B + 1);
+    b->out_off.resize(B);
+    b->out_len.resize(B);
+    b->pc_in.resize(B);
+    b->pc_syn.resize(B);
+    int acc = 0, max_pc = 1;
+    b->frame_off[0] = 0;
+    b->pool_off[0] = 0;
+    for (int i = 0; i < B; ++i) {
+        const int n = n_samples[i];
+        // torch.stft's reflect padding needs n > n_fft/2
+        if (n <= kHalf) { delete b; return AWARE_E_BADARG; }
+        b->in_off[i] = in_offsets ? in_offsets[i] : acc;
+        acc += n;
+        const int T = 1 + n / kHop;
+        b->T[i] = T;
+        b->frame_off[i + 1] = b->frame_off[i] + T;
+        b->pool_off[i + 1] = b->pool_off[i] + T / 2;
+        b->out_off[i] = kHop * (b->frame_off[i] - i);
+        b->out_len[i] = kHop * (T - 1);
+        b->pc_in[i] = (n + 4095) / 4096;
+        int nseg = (T - 1 + kSynthBlocks - 1) / kSynthBlocks;
+        if (nseg < 1) nseg = 1;
+        b->pc_syn[i] = nseg;
+        if (T > b->max_frames) b->max_frames = T;
+        if (n > b->max_len) b->max_len = n;
+        if (b->pc_in[i] > max_pc) max_pc = b->pc_in[i];
+        if (nseg > max_pc) max_pc = nseg;
+    }
+    b->NF = b->frame_off[B];
+    b->NP = b->pool_off[B];
+    b->NS = kHop * (b->NF - B);
+    b->pstride = max_pc;
+    const size_t ints = (size_t)(B + 1) * 2 + (size_t)B * 6;
+    HIPCHK(hipMalloc((void**)&b->d_mem, ints * sizeof(int)));
+    int* d = b->d_mem;
+    auto up = [&](int*& dst, const std::vector<int>& v) -> hipError_t {
+        dst = d;
+        d += v.size();
+        return hipMemcpy(dst, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice);
+    };
+    HIPCHK(up(b->d_frame_off, b->frame_off));
+    HIPCHK(up(b->d_pool_off, b->pool_off));
+    HIPCHK(up(b->d_in_off, b->in_off));
+    HIPCHK(up(b->d_in_len, b->n));
+    HIPCHK(up(b->d_out_off, b->out_off));
+    HIPCHK(up(b->d_out_len, b->out_len));
+    HIPCHK(up(b->d_pc_in, b->pc_in));
+    HIPCHK(up(b->d_pc_syn, b->pc_syn));
+    *out = b;
+    return AWARE_OK;
+}
+extern "C" void aware_batch_destroy(aware_batch* b) {
+    if (!b) return;
+    if (b->d_mem) (void)hipFree(b->d_mem);
+    delete b;
+}
+extern "C" int aware_batch_total_frames(const aware_batch* b) { return b ? b->NF : AWARE_E_BADARG; }
+extern "C" int aware_batch_total_pooled(const aware_batch* b) { return b ? b->NP : AWARE_E_BADARG; }
+extern "C" int aware_batch_total_out(const aware_batch* b) { return b ? b->NS : AWARE_E_BADARG; }
+extern "C" int aware_batch_out_offset(const aware_batch* b, int i) {
+    return (b && i >= 0 && i < b->B) ? b->out_off[i] : AWARE_E_BADARG;
+}
+extern "C" int aware_batch_out_length(const aware_batch* b, int i) {
+    return (b && i >= 0 && i < b->B) ? b->out_len[i] : AWARE_E_BADARG;
+}
+extern "C" int aware_batch_frames(const aware_batch* b, int i) {
+    return (b && i >= 0 && i < b->B) ? b->T[i] : AWARE_E_BADARG;
+}
+extern "C" size_t aware_batch_scratch_bytes(const aware_batch* b) {
+    return b ? (size_t)b->B * b->pstride * sizeof(unsigned long long) + 256 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// workspace carving
+struct Carver {
+    char* base;
+    size_t off = 0, cap;
+    bool ok = true;
+    Carver(void* p, size_t c) : base((char*)p), cap(c) {}
+    template <typename Tp> Tp* take(size_t count) {
+        off = (off + 255) & ~(size_t)255;
+        Tp* r = (Tp*)(base + off);
+        off += count * sizeof(Tp);
+        if (off > cap) ok = false;
+        return r;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int aware_stft(const aware_plan* plan, const aware_batch* b, const float* audio, int normalize, void* spec,
+                          void* scratch, void* stream) {
+    if (!plan || !b || !audio || !spec || (normalize && !scratch)) return AWARE_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long* pmax = (unsigned long long*)scratch;
+    if (normalize) {
+        launch_absmax_partials(audio, b->d_in_off, b->d_in_len, pmax, b->pstride, b->B, b->max_len, st);
+        LAUNCHCHK();
+    }
+    AnalysisLaunch L;
+    L.plan = plan->dev; L.frame_off = b->d_frame_off; L.B = b->B; L.max_frames = b->max_frames;
+    L.sig = audio; L.sig_off = b->d_in_off; L.sig_len = b->d_in_len;
+    L.pmax = normalize ? pmax : nullptr; L.pcount = b->d_pc_in; L.pstride = b->pstride;
+    L.full = spec;
+    launch_analysis(L, st);
+    LAUNCHCHK();
+    return AWARE_OK;
+}
+
+extern "C" int aware_stft_band(const aware_plan* plan, const aware_batch* b, const float* audio, int normalize,
+                               float* mag, void* phasor, void* scratch, void* stream) {
+    if (!plan || !b || !audio || (!mag && !phasor) || (normalize && !scratch)) return AWARE_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long* pmax = (unsigned long long*)scratch;
+    if (normalize) {
+        launch_absmax_partials(audio, b->d_in_off, b->d_in_len, pmax, b->pstride, b->B, b->max_len, st);
+        LAUNCHCHK();
+    }
+    AnalysisLaunch L;
+    L.plan = plan->dev; L.frame_off = b->d_frame_off; L.B = b->B; L.max_frames = b->max_frames;
+    L.sig = audio; L.sig_off = b->d_in_off; L.sig_len = b->d_in_len;
+    L.pmax = normalize ? pmax : nullptr; L.pcount = b->d_pc_in; L.pstride = b->pstride;
+    L.mag = mag; L.unit = phasor; L.unit_default = 1.f;
+    launch_analysis(L, st);
+    LAUNCHCHK();
+    return AWARE_OK;
+}
+
+extern "C" int aware_istft(const aware_plan* plan, const aware_batch* b, const void* spec, int normalize, float* out,
+                           void* scratch, void* stream) {
+    if (!plan || !b || !spec || !out || (normalize && !scratch)) return AWARE_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long* pmax = (unsigned long long*)scratch;
+    SynthLaunch S;
+    S.plan = plan->dev; S.frame_off = b->d_frame_off; S.B = b->B; S.max_frames = b->max_frames;
+    S.full = spec; S.out = out; S.pmax = normalize ? pmax : nullptr; S.pstride = b->pstride;
+    launch_synth(S, st);
+    LAUNCHCHK();
+    if (normalize) {
+        launch_finish(out, b->d_frame_off, pmax, b->d_pc_syn, b->pstride, nullptr, out, b->d_out_off, b->B,
+                      b->max_frames, st);
+        LAUNCHCHK();
+    }
+    return AWARE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int aware_detector_create(aware_detector** out, const aware_plan* plan, const float* mel_basis, int n_mels,
+                                     int n_layers, const int* channels, const float* const* weights,
+                                     const float* const* biases) {
+    if (!out || !plan || !mel_basis || !channels || !weights) return AWARE_E_BADARG;
+    if (n_mels != 128 || n_layers < 1 || n_layers > 7 || channels[0] != n_mels) return AWARE_E_UNSUPPORTED;
+    const int cl = channels[n_layers];
+    if (cl % 2 || cl > 64) return AWARE_E_UNSUPPORTED;
+    for (int i = 0; i <= n_layers; ++i)
+        if (channels[i] % 4) return AWARE_E_UNSUPPORTED;
+    aware_detector* d = new aware_detector();
+    d->n_mels = n_mels; d->n_layers = n_layers; d->nbits = cl / 2;
+    size_t total = (size_t)n_mels * kFS * 2;
+    for (int i = 0; i <= n_layers; ++i) { d->ch[i] = channels[i]; if (channels[i] > d->maxc) d->maxc = channels[i]; }
+    for (int i = 0; i < n_layers; ++i) total += (size_t)channels[i] * channels[i + 1] * 2 + channels[i + 1];
+    std::vector<float> h(total, 0.f);
+    size_t o = 0;
+    const int nbins = kNfft / 2 + 1;
+    const int lo = plan->dev.band_lo, nb = plan->dev.nband;
+    size_t o_melT = o; o += (size_t)n_mels * kFS;
+    size_t o_melB = o; o += (size_t)kFS * n_mels;
+    // only the in-band columns of the mel basis ever multiply non-zero magnitudes
+    // (multibit_embedder.py:104, multibit_detector.py:34-37 zero the rest)
+    for (int j = 0; j < n_mels; ++j)
+        for (int f = 0; f < nb; ++f) {
+            float v = mel_basis[(size_t)j * nbins + lo + f];
+            h[o_melT + (size_t)j * kFS + f] = v;
+            h[o_melB + (size_t)f * n_mels + j] = v;
+        }
+    size_t o_w[8], o_wT[8], o_b[8];
+    for (int l = 0; l < n_layers; ++l) {
+        const int ci = channels[l], co = channels[l + 1];
+        o_w[l] = o; o += (size_t)ci * co;
+        o_wT[l] = o; o += (size_t)ci * co;
+        o_b[l] = o; o += co;
+        for (int r = 0; r < co; ++r)
+            for (int c = 0; c < ci; ++c) {
+                float v = weights[l][(size_t)r * ci + c];
+                h[o_w[l] + (size_t)r * ci + c] = v;
+                h[o_wT[l] + (size_t)c * co + r] = v;
+            }
+        for (int r = 0; r < co; ++r) h[o_b[l] + r] = biases && biases[l] ? biases[l][r] : 0.f;
+    }
+    HIPCHK(hipMalloc((void**)&d->mem, total * sizeof(float)));
+    HIPCHK(hipMemcpy(d->mem, h.data(), total * sizeof(float), hipMemcpyHostToDevice));
+    d->melT = d->mem + o_melT;
+    d->melB = d->mem + o_melB;
+    for (int l = 0; l < n_layers; ++l) { d->w[l] = d->mem + o_w[l]; d->wT[l] = d->mem + o_wT[l]; d->bias[l] = d->mem + o_b[l]; }
+    *out = d;
+    return AWARE_OK;
+}
+extern "C" void aware_detector_destroy(aware_detector* d) {
+    if (!d) return;
+    if (d->mem) (void)hipFree(d->mem);
+    delete d;
+}
+
+// detector activations carved from a workspace
+struct DetBufs {
+    float* xm;        // [NF][128]
+    float* x0;        // [NP][128]
+    float* act[8];    // [NP][C_l+1]
+    float* rstd[8];   // [B][C_l+1]
+    float *mu, *rs, *gstat;
+    float* pred;      // [B][nbits]
+};
+static void carve_det(Carver& c, const aware_batch* b, const aware_detector* d, DetBufs& o) {
+    o.xm = c.take<float>((size_t)b->NF * 128);
+    o.x0 = c.take<float>((size_t)b->NP * 128);
+    for (int l = 0; l < d->n_layers; ++l) {
+        o.act[l] = c.take<float>((size_t)b->NP * d->ch[l + 1]);
+        o.rstd[l] = c.take<float>((size_t)b->B * d->ch[l + 1]);
+    }
+    o.mu = c.take<float>((size_t)b->B * 128);
+    o.rs = c.take<float>((size_t)b->B * 128);
+    o.gstat = c.take<float>((size_t)b->B * 4);
+    o.pred = c.take<float>((size_t)b->B * d->nbits);
+}
+static size_t det_bytes(const aware_batch* b, const aware_detector* d) {
+    size_t f = (size_t)b->NF * 128 + (size_t)b->NP * 128 + (size_t)b->B * (128 * 2 + 4 + d->nbits);
+    for (int l = 0; l < d->n_layers; ++l) f += (size_t)(b->NP + b->B) * d->ch[l + 1];
+    return f * sizeof(float) + 256 * (8 + 2 * d->n_layers);
+}
+
+// forward through the network; mag [NF][256] -> act[last], pred
+static int det_forward(const aware_detector* d, const aware_batch* b, const float* mag, DetBufs& o, hipStream_t st) {
+    launch_gemm_nt(mag, kFS, d->melT, kFS, nullptr, o.xm, 128, b->NF, 128, kFS, st);
+    LAUNCHCHK();
+    launch_mel_norm_fwd(o.xm, b->d_frame_off, b->d_pool_off, o.x0, o.mu, o.rs, o.gstat, b->B, st);
+    LAUNCHCHK();
+    const float* x = o.x0;
+    for (int l = 0; l < d->n_layers; ++l) {
+        const int ci = d->ch[l], co = d->ch[l + 1];
+        launch_gemm_nt(x, ci, d->w[l], ci, d->bias[l], o.act[l], co, b->NP, co, ci, st);
+        LAUNCHCHK();
+        launch_in_lrelu_fwd(o.act[l], b->d_pool_off, o.rstd[l], co, b->B, st);
+        LAUNCHCHK();
+        x = o.act[l];
+    }
+    return AWARE_OK;
+}
+
+extern "C" size_t aware_detect_workspace_bytes(const aware_batch* b, const aware_detector* d) {
+    if (!b || !d) return 0;
+    return det_bytes(b, d) + (size_t)b->NF * kFS * sizeof(float) + aware_batch_scratch_bytes(b) + 1024;
+}
+
+extern "C" int aware_detector_forward(const aware_detector* d, const aware_batch* b, const float* mag, float* values,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+    if (!d || !b || !mag || !values || !workspace) return AWARE_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    Carver c(workspace, workspace_bytes);
+    DetBufs o;
+    carve_det(c, b, d, o);
+    if (!c.ok) return AWARE_E_WORKSPACE;
+    int rc = det_forward(d, b, mag, o, st);
+    if (rc) return rc;
+    launch_head(o.act[d->n_layers - 1], b->d_pool_off, nullptr, values, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
+                d->nbits, b->B, st);
+    LAUNCHCHK();
+    return AWARE_OK;
+}
+
+extern "C" int aware_detect(const aware_plan* plan, const aware_detector* d, const aware_batch* b, const float* audio,
+                            float* values, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!plan || !d || !b || !audio || !values || !workspace) return AWARE_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    Carver c(workspace, workspace_bytes);
+    DetBufs o;
+    carve_det(c, b, d, o);
+    float* mag = c.take<float>((size_t)b->NF * kFS);
+    unsigned long long* pmax = c.take<unsigned long long>((size_t)b->B * b->pstride);
+    if (!c.ok) return AWARE_E_WORKSPACE;
+    int rc = aware_stft_band(plan, b, audio, 1, mag, nullptr, pmax, stream);
+    if (rc) return rc;
+    rc = det_forward(d, b, mag, o, st);
+    if (rc) return rc;
+    launch_head(o.act[d->n_layers - 1], b->d_pool_off, nullptr, values, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
+                d->nbits, b->B, st);
+    LAUNCHCHK();
+    return AWARE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+struct aware_embed {
+    const aware_plan* plan;
+    const aware_detector* det;
+    const aware_batch* b;
+    aware_embed_config cfg;
+    DetBufs db;
+    // spectral state [NF][256]
+    float *coef, *lo, *hi, *mom, *vel, *best, *mag, *gmag;
+    cf *P, *U;
+    // signals [NS]
+    float *yraw, *oob, *gy;
+    // gradient ping-pong [NP][maxc]
+    float *d1, *d2;
+    // scalars
+    float *loss, *best_loss, *target;
+    int *improved, *step;
+    float4* sched;
+    unsigned long long *pmaxA, *pmaxY;
+    double* pdot;
+    float hyp[4];
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    hipStream_t cap = nullptr;        // private stream used only to record the graph
+};
+
+static size_t embed_bytes(const aware_batch* b, const aware_detector* d, int iters) {
+    size_t bytes = det_bytes(b, d);
+    bytes += (size_t)b->NF * kFS * sizeof(float) * 8;
+    bytes += (size_t)b->NF * kFS * sizeof(cf) * 2;
+    bytes += (size_t)b->NS * sizeof(float) * 3;
+    bytes += (size_t)b->NP * d->maxc * sizeof(float) * 2;
+    bytes += (size_t)b->B * (3 * d->nbits + 8) * sizeof(float);
+    bytes += (size_t)(iters + 1) * sizeof(float4);
+    bytes += (size_t)b->B * b->pstride * 8 * 3;
+    return bytes + 256 * 40;
+}
+extern "C" size_t aware_embed_workspace_bytes(const aware_batch* b, const aware_detector* d) {
+    if (!b || !d) return 0;
+    return embed_bytes(b, d, 4096);
+}
+
+extern "C" int aware_embed_create(aware_embed** out, const aware_plan* plan, const aware_detector* det,
+                                  const aware_batch* b, const aware_embed_config* cfg, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+    if (!out || !plan || !det || !b || !cfg || !workspace) return AWARE_E_BADARG;
+    if (cfg->num_iterations < 1 || cfg->num_iterations > 4096 || cfg->loss < 0 || cfg->loss > 3) return AWARE_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    aware_embed* e = new aware_embed();
+    e->plan = plan; e->det = det; e->b = b; e->cfg = *cfg;
+    Carver c(workspace, workspace_bytes);
+    carve_det(c, b, det, e->db);
+    const size_t nsp = (size_t)b->NF * kFS;
+    e->coef = c.take<float>(nsp); e->lo = c.take<float>(nsp); e->hi = c.take<float>(nsp);
+    e->mom = c.take<float>(nsp); e->vel = c.take<float>(nsp); e->best = c.take<float>(nsp);
+    e->mag = c.take<float>(nsp); e->gmag = c.take<float>(nsp);
+    e->P = c.take<cf>(nsp); e->U = c.take<cf>(nsp);
+    e->yraw = c.take<float>(b->NS); e->oob = c.take<float>(b->NS); e->gy = c.take<float>(b->NS);
+    e->d1 = c.take<float>((size_t)b->NP * det->maxc); e->d2 = c.take<float>((size_t)b->NP * det->maxc);
+    e->loss = c.take<float>(b->B); e->best_loss = c.take<float>(b->B);
+    e->target = c.take<float>((size_t)b->B * det->nbits);
+    e->improved = c.take<int>(b->B); e->step = c.take<int>(4);
+    e->sched = c.take<float4>(cfg->num_iterations + 1);
+    e->pmaxA = c.take<unsigned long long>((size_t)b->B * b->pstride);
+    e->pmaxY = c.take<unsigned long long>((size_t)b->B * b->pstride);
+    e->pdot = c.take<double>((size_t)b->B * b->pstride);
+    if (!c.ok) { delete e; return AWARE_E_WORKSPACE; }
+    // torch.optim.NAdam's per-step scalars (torch/optim/nadam.py _single_tensor_nadam):
+    // mu_product lives in a float32 tensor and is read back with .item()
+    std::vector<float4> sc(cfg->num_iterations + 1);
+    float mu_product = 1.0f;
+    const double b1 = cfg->beta1, b2 = cfg->beta2, lr = cfg->lr, md = cfg->momentum_decay;
+    for (int s = 1; s <= cfg->num_iterations; ++s) {
+        double bc2 = 1.0 - pow(b2, (double)s);
+        double mu = b1 * (1.0 - 0.5 * pow(0.96, s * md));
+        double mu_next = b1 * (1.0 - 0.5 * pow(0.96, (s + 1) * md));
+        mu_product = mu_product * (float)mu;
+        double mp = (double)mu_product;
+        sc[s - 1] = make_float4((float)(-lr * (1.0 - mu) / (1.0 - mp)), (float)((-lr * mu_next) / (1.0 - mp * mu_next)),
+                                (float)bc2, 0.f);
+    }
+    sc[cfg->num_iterations] = sc[cfg->num_iterations - 1];
+    HIPCHK(hipMemcpyAsync(e->sched, sc.data(), sc.size() * sizeof(float4), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    e->hyp[0] = (float)(1.0 - b1); e->hyp[1] = (float)b2; e->hyp[2] = (float)(1.0 - b2); e->hyp[3] = cfg->eps;
+    *out = e;
+    return AWARE_OK;
+}
+extern "C" void aware_embed_destroy(aware_embed* e) {
+    if (!e) return;
+    if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
+    if (e->graph) (void)hipGraphDestroy(e->graph);
+    if (e->cap) (void)hipStreamDestroy(e->cap);
+    delete e;
+}
+
+extern "C" void* aware_embed_buffer(aware_embed* e, int which) {
+    if (!e) return nullptr;
+    switch (which) {
+        case 0: return e->loss;
+        case 1: return e->best_loss;
+        case 2: return e->db.pred;
+        case 3: return e->coef;
+        case 4: return e->best;
+        case 5: return e->lo;
+        case 6: return e->hi;
+        case 7: return e->P;
+        case 8: return e->step;
+        case 9: return e->yraw;
+        case 10: return e->mag;
+        default: return nullptr;
+    }
+}
+
+extern "C" int aware_embed_begin(aware_embed* e, const float* audio, const float* target, void* stream) {
+    if (!e || !audio || !target) return AWARE_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const aware_batch* b = e->b;
+    // [WaveformNormalizer, STFT, STFTDecomposer] (multibit_embedder.py:143-147), band only
+    launch_absmax_partials(audio, b->d_in_off, b->d_in_len, e->pmaxA, b->pstride, b->B, b->max_len, st);
+    LAUNCHCHK();
+    AnalysisLaunch L;
+    L.plan = e->plan->dev; L.frame_off = b->d_frame_off; L.B = b->B; L.max_frames = b->max_frames;
+    L.sig = audio; L.sig_off = b->d_in_off; L.sig_len = b->d_in_len;
+    L.pmax = e->pmaxA; L.pcount = b->d_pc_in; L.pstride = b->pstride;
+    L.mag = e->mag; L.unit = e->P; L.unit_default = 1.f;
+    launch_analysis(L, st);
+    LAUNCHCHK();
+    // constant out-of-band part of every synthesis: x/m - istft(band of the original)
+    SynthLaunch S;
+    S.plan = e->plan->dev; S.frame_off = b->d_frame_off; S.B = b->B; S.max_frames = b->max_frames;
+    S.amp = e->mag; S.ph = e->P; S.out = e->gy; S.pstride = b->pstride;
+    launch_synth(S, st);
+    LAUNCHCHK();
+    launch_oob_residual(audio, b->d_in_off, e->pmaxA, b->d_pc_in, b->pstride, e->gy, b->d_frame_off, e->oob, b->B,
+                        b->max_frames, st);
+    LAUNCHCHK();
+    const float ratio = (float)pow(10.0, -(double)e->cfg.tolerance_db / 20.0);
+    launch_embed_prepare(e->mag, e->coef, e->lo, e->hi, e->mom, e->vel, e->best, ratio, (size_t)b->NF * kFS, st);
+    LAUNCHCHK();
+    HIPCHK(hipMemcpyAsync(e->target, target, (size_t)b->B * e->det->nbits * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemsetAsync(e->step, 0, 4 * sizeof(int), st));
+    // best_loss = +inf
+    std::vector<float> inf(b->B, INFINITY);
+    HIPCHK(hipMemcpyAsync(e->best_loss, inf.data(), b->B * sizeof(float), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return AWARE_OK;
+}
+
+// one loop body of AWAREEmbedder._optimize (multibit_embedder.py:95-122)
+static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* grad_out) {
+    const aware_batch* b = e->b;
+    const aware_detector* d = e->det;
+    const int nl = d->n_layers;
+    // :99-103  scatter + Assembler + ISTFT  (out-of-band part is the constant `oob`)
+    SynthLaunch S;
+    S.plan = e->plan->dev; S.frame_off = b->d_frame_off; S.B = b->B; S.max_frames = b->max_frames;
+    S.amp = e->coef; S.ph = e->P; S.out = e->yraw; S.add = e->oob; S.pmax = e->pmaxY; S.pstride = b->pstride;
+    launch_synth(S, st);
+    LAUNCHCHK();
+    // normalise x2 + STFT + |.| on the band (:104 zeroes the rest, so it is never computed)
+    AnalysisLaunch L;
+    L.plan = e->plan->dev; L.frame_off = b->d_frame_off; L.B = b->B; L.max_frames = b->max_frames;
+    L.sig = e->yraw; L.sig_off = b->d_out_off; L.sig_len = b->d_out_len;
+    L.pmax = e->pmaxY; L.pcount = b->d_pc_syn; L.pstride = b->pstride; L.double_norm = 1;
+    L.mag = e->mag; L.unit = e->U; L.unit_default = 0.f;
+    launch_analysis(L, st);
+    LAUNCHCHK();
+    // :107 detector forward
+    int rc = det_forward(d, b, e->mag, e->db, st);
+    if (rc) return rc;
+    // :109 loss, :120-122 best tracking, gradient seed
+    float* dA = e->d1;
+    float* dB = e->d2;
+    launch_head(e->db.act[nl - 1], b->d_pool_off, e->target, e->db.pred, e->loss, e->best_loss, e->improved, dA, e->step,
+                e->cfg.loss, d->nbits, b->B, st);
+    LAUNCHCHK();
+    // :111 backward through the detector (data gradients only; weights are frozen :76-77)
+    for (int l = nl - 1; l >= 0; --l) {
+        const int ci = d->ch[l], co = d->ch[l + 1];
+        launch_in_lrelu_bwd(dA, e->db.act[l], b->d_pool_off, e->db.rstd[l], co, b->B, st);
+        LAUNCHCHK();
+        launch_gemm_nt(dA, co, d->wT[l], co, nullptr, dB, ci, b->NP, ci, co, st);
+        LAUNCHCHK();
+        float* t = dA; dA = dB; dB = t;
+    }
+    launch_mel_norm_bwd(dA, e->db.xm, b->d_frame_off, b->d_pool_off, e->db.mu, e->db.rs, e->db.gstat, b->B, st);
+    LAUNCHCHK();
+    launch_gemm_nt(e->db.xm, 128, d->melB, 128, nullptr, e->gmag, kFS, b->NF, kFS, 128, st);
+    LAUNCHCHK();
+    // backward through |.|, STFT, reflect padding
+    SynthLaunch SA;
+    SA.plan = e->plan->dev; SA.frame_off = b->d_frame_off; SA.B = b->B; SA.max_frames = b->max_frames;
+    SA.amp = e->gmag; SA.ph = e->U; SA.out = e->gy; SA.adjoint = 1; SA.yraw = e->yraw; SA.pmax_in = e->pmaxY;
+    SA.pcount = b->d_pc_syn; SA.pdot = e->pdot; SA.pstride = b->pstride;
+    launch_synth(SA, st);
+    LAUNCHCHK();
+    // backward through the normalisers, ISTFT and the assembler; :112-117 NAdam + clamp
+    AnalysisLaunch LA;
+    LA.plan = e->plan->dev; LA.frame_off = b->d_frame_off; LA.B = b->B; LA.max_frames = b->max_frames;
+    LA.sig = e->gy; LA.sig_off = b->d_out_off; LA.sig_len = b->d_out_len;
+    LA.pmax = e->pmaxY; LA.pcount = b->d_pc_syn; LA.pstride = b->pstride;
+    LA.adjoint = 1; LA.yraw = e->yraw; LA.pdot = e->pdot; LA.phasor = e->P;
+    LA.coef = e->coef; LA.mom = e->mom; LA.vel = e->vel; LA.lo = e->lo; LA.hi = e->hi; LA.best = e->best;
+    LA.improved = e->improved; LA.sched = e->sched; LA.step = e->step; LA.grad_out = grad_out; LA.do_step = do_step;
+    memcpy(LA.hyp, e->hyp, sizeof(LA.hyp));
+    launch_analysis(LA, st);
+    LAUNCHCHK();
+    if (do_step) {
+        launch_advance_step(e->step, st);
+        LAUNCHCHK();
+    }
+    return AWARE_OK;
+}
+
+extern "C" int aware_embed_iterate(aware_embed* e, int n_iters, void* stream) {
+    if (!e || n_iters < 0) return AWARE_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (!e->cfg.use_graph) {
+        for (int i = 0; i < n_iters; ++i) {
+            int rc = embed_iteration(e, st, 1, nullptr);
+            if (rc) return rc;
+        }
+        return AWARE_OK;
+    }
+    if (!e->gexec) {
+        // the caller's stream may be the legacy default stream, which cannot be captured:
+        // record the iteration on a private stream, replay it on the caller's
+        if (!e->cap) HIPCHK(hipStreamCreateWithFlags(&e->cap, hipStreamNonBlocking));
+        HIPCHK(hipStreamBeginCapture(e->cap, hipStreamCaptureModeThreadLocal));
+        int rc = embed_iteration(e, e->cap, 1, nullptr);
+        hipError_t ce = hipStreamEndCapture(e->cap, &e->graph);
+        if (rc) return rc;
+        HIPCHK(ce);
+        HIPCHK(hipGraphInstantiate(&e->gexec, e->graph, nullptr, nullptr, 0));
+    }
+    for (int i = 0; i < n_iters; ++i) HIPCHK(hipGraphLaunch(e->gexec, st));
+    return AWARE_OK;
+}
+
+extern "C" int aware_embed_gradient(aware_embed* e, float* grad, void* stream) {
+    if (!e || !grad) return AWARE_E_BADARG;
+    return embed_iteration(e, (hipStream_t)stream, 0, grad);
+}
+
+extern "C" int aware_embed_finish(aware_embed* e, const float* rescale, float* out, void* stream) {
+    if (!e || !out) return AWARE_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const aware_batch* b = e->b;
+    SynthLaunch S;
+    S.plan = e->plan->dev; S.frame_off = b->d_frame_off; S.B = b->B; S.max_frames = b->max_frames;
+    S.amp = e->best; S.ph = e->P; S.out = e->yraw; S.add = e->oob; S.pmax = e->pmaxY; S.pstride = b->pstride;
+    launch_synth(S, st);
+    LAUNCHCHK();
+    launch_finish(e->yraw, b->d_frame_off, e->pmaxY, b->d_pc_syn, b->pstride, rescale, out, b->d_out_off, b->B,
+                  b->max_frames, st);
+    LAUNCHCHK();
+    return AWARE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int aware_pcm_quantize(const float* in, float* out, const int* off, const int* len, int B, int max_len,
+                                  int bits, void* scratch, void* stream) {
+    if (!in || !out || !off || !len || !scratch || B < 1) return AWARE_E_BADARG;
+    float q, lo, hi;
+    switch (bits) {   // scripts/attacks.py:52-67 (the "12-bit" branch really is 13-bit)
+        case 8: q = 127.f; lo = -128.f; hi = 127.f; break;
+        case 12: q = 4095.f; lo = -4096.f; hi = 4095.f; break;
+        case 16: q = 32767.f; lo = -32768.f; hi = 32767.f; break;
+        case 24: q = 8388607.f; lo = -8388608.f; hi = 8388607.f; break;
+        default: return AWARE_E_BADARG;   // reference raises ValueError
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int ps = (max_len + 4095) / 4096;
+    unsigned long long* pmax = (unsigned long long*)scratch;
+    int* pcount = (int*)(pmax + (size_t)B * ps);
+    // pcount[b] = ceil(len/4096): computed on device by a tiny kernel would need another launch;
+    // the caller's `len` is a device array, so derive the counts with the partial kernel's own rule
+    // by zero-filling the partials first (a zero partial never wins the max).
+    HIPCHK(hipMemsetAsync(pmax, 0, (size_t)B * ps * sizeof(unsigned long long), st));
+    launch_absmax_partials(in, off, len, pmax, ps, B, max_len, st);
+    LAUNCHCHK();
+    std::vector<int> pc(B, ps);
+    HIPCHK(hipMemcpyAsync(pcount, pc.data(), B * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    launch_pcm_quantize(in, out, off, len, pmax, pcount, ps, q, lo, hi, B, max_len, st);
+    LAUNCHCHK();
+    return AWARE_OK;
+}
+
+extern "C" int aware_upfirdn(const float* in, const int* in_off, const int* in_len, float* out, const int* out_off,
+                             const int* out_len, int B, int max_out, const float* h, int nh, int up, int down,
+                             int half_len, void* stream) {
+    if (!in || !out || !h || B < 1 || up < 1 || down < 1) return AWARE_E_BADARG;
+    launch_upfirdn(in, in_off, in_len, out, out_off, out_len, h, nh, up, down, half_len, B, max_out,
+                   (hipStream_t)stream);
+    LAUNCHCHK();
+    return AWARE_OK;
+}
+
+extern "C" int aware_iir(const float* in, const int* off, const int* len, int B, int max_len, void* out, int out_f64,
+                         const double* b, const double* a, const double* zi, int ncoef, int filtfilt, void* scratch,
+                         void* stream) {
+    if (!in || !out || !b || !a || B < 1 || ncoef < 2 || ncoef > 12) return AWARE_E_BADARG;
+    if (filtfilt && (!zi || !scratch)) return AWARE_E_BADARG;
+    launch_iir_full(in, off, len, out, out_f64, b, a, zi, ncoef, filtfilt ? 1 : 0, (double*)scratch,
+                    max_len + 6 * ncoef, B, (hipStream_t)stream);
+    LAUNCHCHK();
+    return AWARE_OK;
+}
+
+extern "C" int aware_segment_cut(const float* in, const int* in_off, float* out, const int* out_off,
+                                 const int* out_len, const int* cut_start, const int* cut_len, int zero_fill, int B,
+                                 int max_len, void* stream) {
+    if (!in || !out || B < 1) return AWARE_E_BADARG;
+    launch_segment_copy(in, in_off, out, out_off, out_len, cut_start, cut_len, zero_fill, B, max_len,
+                        (hipStream_t)stream);
+    LAUNCHCHK();
+    return AWARE_OK;
+}
+
+extern "C" int aware_gaussian_noise(const float* in, float* out, const int* off, const int* len, int B, int max_len,
+                                    const uint32_t* seeds, float snr_db, void* scratch, void* stream) {
+    if (!in || !out || !seeds || !scratch || B < 1) return AWARE_E_BADARG;
+    launch_gaussian_noise_full(in, out, off, len, seeds, (double*)scratch, snr_db, B, max_len, (hipStream_t)stream);
+    LAUNCHCHK();
+    return AWARE_OK;
+}
+
+extern "C" int aware_gemm_nt(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc,
+                             int M, int N, int K, void* stream) {
+    if (!A || !Bt || !C || M < 1 || N < 1 || K < 4 || (K & 3) || (lda & 3) || (ldb & 3)) return AWARE_E_BADARG;
+    launch_gemm_nt(A, lda, Bt, ldb, bias, C, ldc, M, N, K, (hipStream_t)stream);
+    LAUNCHCHK();
+    return AWARE_OK;
+}

@@ -1,0 +1,113 @@
+// Shared device helpers and internal structures for libaware_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fft512.hpp"
+
+namespace aware {
+
+// Band-limited spectral arrays are frame-major: [global frame][kFS] with the first
+// `nband` entries valid (bin k = band_lo + f) and the tail zero.  kFS = 256 keeps
+// every frame row 1 KiB-aligned and makes the row the K dimension of the mel GEMM.
+constexpr int kFS = 256;
+constexpr int kFramesPerWG = 16;     // frames transformed by one 256-thread workgroup
+constexpr int kSynthBlocks = 13;     // hop blocks of output per synthesis workgroup (16 - 3 halo)
+constexpr int kChunk = (kFramesPerWG + 3) * kHop;   // 4864 floats of LDS signal / OLA buffer
+constexpr int kThreads = 256;
+
+// Device-resident plan tables (created by aware_plan_create).
+struct PlanDev {
+    const cf* tw512;      // exp(-2 pi i j/512),  j < 512
+    const cf* tw1024;     // exp(-2 pi i j/1024), j < 512
+    const float* window;  // w[1024]
+    const float* window2; // w^2[1024]
+    int band_lo;          // first band bin (32)
+    int nband;            // number of band bins (225)
+};
+
+// A ragged batch of clips.  frame_off has B+1 entries (prefix sums of T_b).
+// A clip's "istft-length" signal (Ny_b = 256*(T_b-1) samples) lives at float offset
+// 256*(frame_off[b] - b) of any per-clip signal array.
+struct Batch {
+    const int* frame_off;
+    int B;
+};
+
+__device__ __forceinline__ int sig_offset(const int* frame_off, int b) { return kHop * (frame_off[b] - b); }
+
+// per-clip maximum of |y| with the first index attaining it, packed so that an
+// unsigned max gives (largest value, smallest index)
+__device__ __forceinline__ unsigned long long pack_max(float a, unsigned idx) {
+    return ((unsigned long long)__float_as_uint(a) << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+}
+__device__ __forceinline__ unsigned long long umax64(unsigned long long a, unsigned long long b) { return a > b ? a : b; }
+
+__device__ __forceinline__ unsigned long long wave_max64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned lo = __shfl_xor((unsigned)(v & 0xFFFFFFFFu), o);
+        unsigned hi = __shfl_xor((unsigned)(v >> 32), o);
+        v = umax64(v, ((unsigned long long)hi << 32) | lo);
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Normaliser state of one clip, rebuilt by every consumer workgroup from the
+// per-segment partial maxima (deterministic, no atomics, nothing to reset).
+//   m  = max|y| + 1e-8            (WaveformNormalizer, waveform.py:18-19)
+//   m2 = max|y/m| + 1e-8          (the second normaliser of the plugin lists)
+struct ClipNorm {
+    float m, m2;
+    unsigned k;      // index of the first sample attaining max|y|
+};
+
+// all threads of the block call this; `red` is a __shared__ u64[4]
+__device__ __forceinline__ ClipNorm clip_norm_from_partials(const unsigned long long* part, int nseg,
+                                                            unsigned long long* red) {
+    unsigned long long v = 0;
+    for (int i = threadIdx.x; i < nseg; i += blockDim.x) v = umax64(v, part[i]);
+    v = wave_max64(v);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    v = umax64(umax64(red[0], red[1]), umax64(red[2], red[3]));
+    __syncthreads();
+    ClipNorm c;
+    float raw = __uint_as_float((unsigned)(v >> 32));
+    c.k = 0xFFFFFFFFu - (unsigned)(v & 0xFFFFFFFFu);
+    c.m = raw + 1e-8f;
+    c.m2 = raw / c.m + 1e-8f;
+    return c;
+}
+
+// sum of squared windows at padded position p for a clip of T frames
+__device__ __forceinline__ float ola_envelope(const float* __restrict__ w2, int p, int T) {
+    int thi = p >> 8;                    // floor(p/256)
+    int tlo = thi - 3;
+    if (tlo < 0) tlo = 0;
+    if (thi > T - 1) thi = T - 1;
+    float e = 0.f;
+    for (int t = tlo; t <= thi; ++t) e += w2[p - kHop * t];
+    return e;
+}
+
+// balanced split of `nblk` hop blocks into nseg = ceil(nblk/13) segments
+__device__ __forceinline__ void synth_segment(int nblk, int seg, int& nseg, int& jb0, int& jb1) {
+    nseg = (nblk + kSynthBlocks - 1) / kSynthBlocks;
+    if (nseg < 1) nseg = 1;
+    int base = nblk / nseg, rem = nblk % nseg;
+    jb0 = seg * base + (seg < rem ? seg : rem);
+    jb1 = jb0 + base + (seg < rem ? 1 : 0);
+}
+
+}  // namespace aware

@@ -1,0 +1,403 @@
+// Detector network kernels for gfx950: fp32 MFMA GEMM (1x1 convolutions and the mel
+// projection are dense contractions over channels) plus the normalisation /
+// activation / read-out kernels and their hand-written backward passes.
+//
+// Activations are TIME-MAJOR: a clip's frames are consecutive rows and the channel
+// dimension is contiguous, [rows][C].  A 1x1 Conv1d (weight [Cout][Cin]) is then
+//     Z[rows][Cout] = X[rows][Cin] * W[Cout][Cin]^T
+// i.e. an "NT" GEMM whose two operands are both contiguous along the reduction
+// dimension, which is what the f32 MFMA fragments want (one ds_read_b128 = four
+// k-steps).  The data-gradient uses the pre-transposed weight the same way.
+//
+// Reference (all under /root/reference/src/AWARE/detection):
+//   multibit_detector_net.py:109-140 forward; modules/mel.py:185-201 (mel matmul);
+//   modules/conv1d.py:38-42 (conv -> InstanceNorm1d -> LeakyReLU(0.2));
+//   modules/globalStandardize.py:16-21; modules/BRH.py:16-27;
+//   embedding/losses.py:38-42 (push_extremes) and :12-14,:23-25,:68-70.
+#include "common.hpp"
+#include "kernels.h"
+
+namespace aware {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------
+// fp32 MFMA GEMM, C = A * Bt^T + bias.  256 threads = 2x2 waves, BK = 32.
+// LDS rows are padded to 36 floats: the 16-lane groups of ds_read_b128 then hit 64
+// distinct banks.  Within each group of 8 k, lane half h = lane>>5 takes k = 4h..4h+3
+// as four MFMA steps (any k permutation is legal as long as A and B agree).
+// ---------------------------------------------------------------------------------
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, int lda,
+                                                      const float* __restrict__ Bt, int ldb,
+                                                      const float* __restrict__ bias, float* __restrict__ C, int ldc,
+                                                      int M, int N, int K, int tiles_n, int ntiles) {
+    constexpr int BK = 32, LD = 36;
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int LA = BM / 32, LB = BN / 32;          // float4 loads per thread per tile
+    __shared__ float As[BM * LD];
+    __shared__ float Bs[BN * LD];
+
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, so give each
+    // XCD a contiguous run of tiles (tiles of one row panel share A through that XCD's L2)
+    int id = blockIdx.x;
+    if ((ntiles & 7) == 0) id = (id & 7) * (ntiles >> 3) + (id >> 3);
+    const int bm = (id / tiles_n) * BM;
+    const int bn = (id % tiles_n) * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int lrow = tid >> 3, lkq = (tid & 7) * 4;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    float4 ra[LA], rb[LB];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            int r = bm + lrow + 32 * i, k = k0 + lkq;
+            ra[i] = (r < M && k < K) ? *reinterpret_cast<const float4*>(A + (size_t)r * lda + k) : make_float4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            int r = bn + lrow + 32 * i, k = k0 + lkq;
+            rb[i] = (r < N && k < K) ? *reinterpret_cast<const float4*>(Bt + (size_t)r * ldb + k) : make_float4(0, 0, 0, 0);
+        }
+    };
+    auto sstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) *reinterpret_cast<float4*>(&As[(lrow + 32 * i) * LD + lkq]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < LB; ++i) *reinterpret_cast<float4*>(&Bs[(lrow + 32 * i) * LD + lkq]) = rb[i];
+    };
+
+    gload(0);
+    sstore();
+    __syncthreads();
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        const bool more = (k0 + BK) < K;
+        if (more) gload(k0 + BK);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = *reinterpret_cast<const float4*>(&As[(wm * WM + i * 32 + li) * LD + 8 * g + 4 * lh]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bf[j] = *reinterpret_cast<const float4*>(&Bs[(wn * WN + j * 32 + li) * LD + 8 * g + 4 * lh]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+        if (more) {
+            sstore();
+            __syncthreads();
+        }
+    }
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = bn + wn * WN + j * 32 + li;
+            const float bv = (bias && col < N) ? bias[col] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = bm + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (row < M && col < N) C[(size_t)row * ldc + col] = acc[i][j][e] + bv;
+            }
+        }
+}
+
+void launch_gemm_nt(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc, int M,
+                    int N, int K, hipStream_t st) {
+    // pick the tile whose grid wastes the fewest CU-rounds (256 CUs)
+    auto rounds = [&](int bm, int bn) {
+        long t = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+        long r = (t + 255) / 256;
+        return (double)r * bm * bn;             // cost ~ rounds * tile area
+    };
+    const bool narrow = N <= 64;
+    if (!narrow && rounds(128, 128) <= rounds(128, 64)) {
+        int tn = (N + 127) / 128, tm = (M + 127) / 128;
+        hipLaunchKernelGGL((gemm_nt_kernel<128, 128>), dim3(tn * tm), dim3(256), 0, st, A, lda, Bt, ldb, bias, C, ldc, M,
+                           N, K, tn, tn * tm);
+    } else {
+        int tn = (N + 63) / 64, tm = (M + 127) / 128;
+        hipLaunchKernelGGL((gemm_nt_kernel<128, 64>), dim3(tn * tm), dim3(256), 0, st, A, lda, Bt, ldb, bias, C, ldc, M,
+                           N, K, tn, tn * tm);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// block reductions (256 threads)
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// ---------------------------------------------------------------------------------
+// mel block: InstanceNorm1d(128) over time -> GlobalStandardize (per clip, unbiased
+// std) -> AvgPool1d(2,2).  One workgroup per clip: 128 channels x 2 row groups.
+// gstat[b] = {global mean a, 1/(s+1e-8), s, n}
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mel_norm_fwd_kernel(const float* __restrict__ xm, const int* __restrict__ frame_off,
+                                                            const int* __restrict__ pool_off, float* __restrict__ x0,
+                                                            float* __restrict__ mu_out, float* __restrict__ rs_out,
+                                                            float* __restrict__ gstat) {
+    __shared__ float s1[2][128], s2[2][128], smu[128], srs[128], red[4];
+    const int b = blockIdx.x;
+    const int f0 = frame_off[b], T = frame_off[b + 1] - f0;
+    const int c = threadIdx.x & 127, g = threadIdx.x >> 7;
+    const float* x = xm + (size_t)f0 * 128;
+    float a = 0.f;
+    for (int t = g; t < T; t += 2) a += x[(size_t)t * 128 + c];
+    s1[g][c] = a;
+    __syncthreads();
+    const float mu = (s1[0][c] + s1[1][c]) / (float)T;
+    float q = 0.f, d1 = 0.f;
+    for (int t = g; t < T; t += 2) { float d = x[(size_t)t * 128 + c] - mu; q += d * d; d1 += d; }
+    s2[g][c] = q;
+    __syncthreads();
+    s1[g][c] = d1;
+    __syncthreads();
+    const float var = (s2[0][c] + s2[1][c]) / (float)T;           // biased, eps 1e-5
+    const float rs = 1.0f / sqrtf(var + 1e-5f);
+    if (g == 0) { smu[c] = mu; srs[c] = rs; mu_out[b * 128 + c] = mu; rs_out[b * 128 + c] = rs; }
+    // global statistics of u = (x - mu) * rs over all T*128 elements
+    float su = 0.f, suu = 0.f;
+    if (g == 0) { su = rs * (s1[0][c] + s1[1][c]); suu = rs * rs * (s2[0][c] + s2[1][c]); }
+    su = block_sum(su, red);
+    suu = block_sum(suu, red);
+    const float n = (float)T * 128.f;
+    const float ga = su / n;
+    float ss = suu - n * ga * ga;
+    if (ss < 0.f) ss = 0.f;
+    const float gs = sqrtf(ss / (n - 1.f));                       // unbiased std
+    const float ginv = 1.0f / (gs + 1e-8f);
+    if (threadIdx.x == 0) { gstat[b * 4 + 0] = ga; gstat[b * 4 + 1] = ginv; gstat[b * 4 + 2] = gs; gstat[b * 4 + 3] = n; }
+    const int Tp = T / 2;
+    float* o = x0 + (size_t)pool_off[b] * 128;
+    for (int t = g; t < Tp; t += 2) {
+        float u0 = (x[(size_t)(2 * t) * 128 + c] - mu) * rs;
+        float u1 = (x[(size_t)(2 * t + 1) * 128 + c] - mu) * rs;
+        o[(size_t)t * 128 + c] = 0.5f * ((u0 - ga) * ginv + (u1 - ga) * ginv);
+    }
+}
+
+// backward of the mel block, in place on xm (xm <- dL/dxm)
+__global__ __launch_bounds__(256) void mel_norm_bwd_kernel(const float* __restrict__ dx0, float* __restrict__ xm,
+                                                            const int* __restrict__ frame_off, const int* __restrict__ pool_off,
+                                                            const float* __restrict__ mu_in, const float* __restrict__ rs_in,
+                                                            const float* __restrict__ gstat) {
+    __shared__ float s1[2][128], s2[2][128], red[4];
+    const int b = blockIdx.x;
+    const int f0 = frame_off[b], T = frame_off[b + 1] - f0, Tp = T / 2;
+    const int c = threadIdx.x & 127, g = threadIdx.x >> 7;
+    float* x = xm + (size_t)f0 * 128;
+    const float* d0 = dx0 + (size_t)pool_off[b] * 128;
+    const float mu = mu_in[b * 128 + c], rs = rs_in[b * 128 + c];
+    const float ga = gstat[b * 4 + 0], ginv = gstat[b * 4 + 1], gs = gstat[b * 4 + 2], n = gstat[b * 4 + 3];
+    // pass A: sum dv and sum dv*(u-a) over the whole clip (dv = dx0/2 on pooled frames)
+    float sa = 0.f, sb = 0.f;
+    for (int t = g; t < 2 * Tp; t += 2) {
+        float dv = 0.5f * d0[(size_t)(t >> 1) * 128 + c];
+        float u = (x[(size_t)t * 128 + c] - mu) * rs;
+        sa += dv; sb += dv * (u - ga);
+    }
+    sa = block_sum(sa, red);
+    sb = block_sum(sb, red);
+    const float mdv = sa / n;
+    const float Q = (gs > 0.f) ? sb * ginv * ginv / ((n - 1.f) * gs) : 0.f;
+    // pass B: per-channel sums of du and du*u
+    float p1 = 0.f, p2 = 0.f;
+    for (int t = g; t < T; t += 2) {
+        float dv = (t < 2 * Tp) ? 0.5f * d0[(size_t)(t >> 1) * 128 + c] : 0.f;
+        float u = (x[(size_t)t * 128 + c] - mu) * rs;
+        float du = (dv - mdv) * ginv - (u - ga) * Q;
+        p1 += du; p2 += du * u;
+    }
+    s1[g][c] = p1; s2[g][c] = p2;
+    __syncthreads();
+    const float m1 = (s1[0][c] + s1[1][c]) / (float)T, m2 = (s2[0][c] + s2[1][c]) / (float)T;
+    // pass C: InstanceNorm backward, overwrite x
+    for (int t = g; t < T; t += 2) {
+        float dv = (t < 2 * Tp) ? 0.5f * d0[(size_t)(t >> 1) * 128 + c] : 0.f;
+        float u = (x[(size_t)t * 128 + c] - mu) * rs;
+        float du = (dv - mdv) * ginv - (u - ga) * Q;
+        x[(size_t)t * 128 + c] = rs * (du - m1 - u * m2);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// conv block tail: InstanceNorm1d over time (biased var, eps 1e-5) + LeakyReLU(0.2),
+// in place.  Workgroup = (64 channels) x (4 row groups) of one clip.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void in_lrelu_fwd_kernel(float* __restrict__ z, const int* __restrict__ pool_off,
+                                                            float* __restrict__ rstd, int C) {
+    __shared__ float s[4][64];
+    const int b = blockIdx.y, c0 = blockIdx.x * 64;
+    const int r0 = pool_off[b], Tp = pool_off[b + 1] - r0;
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6, c = c0 + cl;
+    if (Tp <= 0) return;
+    const bool ok = c < C;
+    float* x = z + (size_t)r0 * C + c;
+    float a = 0.f;
+    if (ok) for (int t = g; t < Tp; t += 4) a += x[(size_t)t * C];
+    s[g][cl] = a;
+    __syncthreads();
+    const float mu = (s[0][cl] + s[1][cl] + s[2][cl] + s[3][cl]) / (float)Tp;
+    __syncthreads();
+    float q = 0.f;
+    if (ok) for (int t = g; t < Tp; t += 4) { float d = x[(size_t)t * C] - mu; q += d * d; }
+    s[g][cl] = q;
+    __syncthreads();
+    const float rs = 1.0f / sqrtf((s[0][cl] + s[1][cl] + s[2][cl] + s[3][cl]) / (float)Tp + 1e-5f);
+    if (ok && g == 0) rstd[(size_t)b * C + c] = rs;
+    if (ok) for (int t = g; t < Tp; t += 4) {
+        float u = (x[(size_t)t * C] - mu) * rs;
+        x[(size_t)t * C] = u > 0.f ? u : 0.2f * u;
+    }
+}
+
+__global__ __launch_bounds__(256) void in_lrelu_bwd_kernel(float* __restrict__ dA, const float* __restrict__ A,
+                                                            const int* __restrict__ pool_off, const float* __restrict__ rstd,
+                                                            int C) {
+    __shared__ float s1[4][64], s2[4][64];
+    const int b = blockIdx.y, c0 = blockIdx.x * 64;
+    const int r0 = pool_off[b], Tp = pool_off[b + 1] - r0;
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6, c = c0 + cl;
+    if (Tp <= 0) return;
+    const bool ok = c < C;
+    float* d = dA + (size_t)r0 * C + c;
+    const float* a = A + (size_t)r0 * C + c;
+    float p1 = 0.f, p2 = 0.f;
+    if (ok) for (int t = g; t < Tp; t += 4) {
+        float av = a[(size_t)t * C];
+        float u = av > 0.f ? av : av * 5.0f;            // invert LeakyReLU(0.2)
+        float du = d[(size_t)t * C] * (av > 0.f ? 1.f : 0.2f);
+        p1 += du; p2 += du * u;
+    }
+    s1[g][cl] = p1; s2[g][cl] = p2;
+    __syncthreads();
+    const float m1 = (s1[0][cl] + s1[1][cl] + s1[2][cl] + s1[3][cl]) / (float)Tp;
+    const float m2 = (s2[0][cl] + s2[1][cl] + s2[2][cl] + s2[3][cl]) / (float)Tp;
+    const float rs = ok ? rstd[(size_t)b * C + c] : 0.f;
+    if (ok) for (int t = g; t < Tp; t += 4) {
+        float av = a[(size_t)t * C];
+        float u = av > 0.f ? av : av * 5.0f;
+        float du = d[(size_t)t * C] * (av > 0.f ? 1.f : 0.2f);
+        d[(size_t)t * C] = rs * (du - m1 - u * m2);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// BRH read-out + loss + gradient seed.  One 64-thread workgroup per clip.
+// loss_kind: 0 push_extremes, 1 mse, 2 hinge, 3 sign  (embedding/losses.py)
+// If dA3 == nullptr only the prediction is produced (detect path).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void head_kernel(const float* __restrict__ a3, const int* __restrict__ pool_off,
+                                                   const float* __restrict__ target, float* __restrict__ pred,
+                                                   float* __restrict__ loss_out, float* __restrict__ best_loss,
+                                                   int* __restrict__ improved, float* __restrict__ dA3, int loss_kind,
+                                                   int nbits) {
+    __shared__ float mean[64], dm[64];
+    const int b = blockIdx.x, c = threadIdx.x;
+    const int r0 = pool_off[b], Tp = pool_off[b + 1] - r0;
+    const int C = 2 * nbits;
+    float m = 0.f;
+    if (c < C) {
+        for (int t = 0; t < Tp; ++t) m += a3[(size_t)(r0 + t) * C + c];
+        m /= (float)Tp;
+    }
+    mean[c] = m;
+    __syncthreads();
+    float lterm = 0.f, dp = 0.f, p = 0.f;
+    if (c < nbits) {
+        p = tanhf(mean[2 * c] - mean[2 * c + 1]);
+        pred[b * nbits + c] = p;
+        if (target) {
+            const float tg = target[b * nbits + c];
+            const float inv = 1.0f / (float)nbits;
+            if (loss_kind == 0) {
+                lterm = ((p - tg) * (p - tg) - 0.1f * fabsf(p)) * inv;
+                dp = (2.f * (p - tg) - 0.1f * ((p > 0.f) ? 1.f : (p < 0.f ? -1.f : 0.f))) * inv;
+            } else if (loss_kind == 1) {
+                lterm = (p - tg) * (p - tg) * inv;
+                dp = 2.f * (p - tg) * inv;
+            } else if (loss_kind == 2) {
+                float h = 1.f - p * tg;
+                lterm = (h > 0.f ? h : 0.f) * inv;
+                dp = (h > 0.f ? -tg : 0.f) * inv;
+            } else {
+                float h = -p * tg;
+                lterm = (h > 0.f ? h : 0.f) * inv;
+                dp = (h > 0.f ? -tg : 0.f) * inv;
+            }
+        }
+    }
+    if (!target) return;
+    float L = wave_sum(lterm);
+    if (c == 0) {
+        loss_out[b] = L;
+        const float bl = best_loss[b];
+        const int imp = L < bl;
+        improved[b] = imp;
+        if (imp) best_loss[b] = L;
+    }
+    if (!dA3) return;
+    const float dpre = dp * (1.f - p * p);                 // tanh'
+    if (c < nbits) { dm[2 * c] = dpre; dm[2 * c + 1] = -dpre; }
+    __syncthreads();
+    if (c < C) {
+        const float gv = dm[c] / (float)Tp;
+        for (int t = 0; t < Tp; ++t) dA3[(size_t)(r0 + t) * C + c] = gv;
+    }
+}
+
+__global__ void advance_step_kernel(int* step) { if (threadIdx.x == 0 && blockIdx.x == 0) *step += 1; }
+
+void launch_mel_norm_fwd(const float* xm, const int* frame_off, const int* pool_off, float* x0, float* mu, float* rs,
+                         float* gstat, int B, hipStream_t st) {
+    hipLaunchKernelGGL(mel_norm_fwd_kernel, dim3(B), dim3(256), 0, st, xm, frame_off, pool_off, x0, mu, rs, gstat);
+}
+void launch_mel_norm_bwd(const float* dx0, float* xm, const int* frame_off, const int* pool_off, const float* mu,
+                         const float* rs, const float* gstat, int B, hipStream_t st) {
+    hipLaunchKernelGGL(mel_norm_bwd_kernel, dim3(B), dim3(256), 0, st, dx0, xm, frame_off, pool_off, mu, rs, gstat);
+}
+void launch_in_lrelu_fwd(float* z, const int* pool_off, float* rstd, int C, int B, hipStream_t st) {
+    hipLaunchKernelGGL(in_lrelu_fwd_kernel, dim3((C + 63) / 64, B), dim3(256), 0, st, z, pool_off, rstd, C);
+}
+void launch_in_lrelu_bwd(float* dA, const float* A, const int* pool_off, const float* rstd, int C, int B,
+                         hipStream_t st) {
+    hipLaunchKernelGGL(in_lrelu_bwd_kernel, dim3((C + 63) / 64, B), dim3(256), 0, st, dA, A, pool_off, rstd, C);
+}
+void launch_head(const float* a3, const int* pool_off, const float* target, float* pred, float* loss,
+                 float* best_loss, int* improved, float* dA3, int* step, int loss_kind, int nbits, int B,
+                 hipStream_t st) {
+    hipLaunchKernelGGL(head_kernel, dim3(B), dim3(64), 0, st, a3, pool_off, target, pred, loss, best_loss, improved, dA3,
+                       loss_kind, nbits);
+    (void)step;
+}
+void launch_advance_step(int* step, hipStream_t st) { hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(64), 0, st, step); }
+
+}  // namespace aware

@@ -1,0 +1,499 @@
+// Framed STFT / iSTFT kernels and their adjoints for gfx950 (MI355X).
+//
+// One 256-thread workgroup = 4 wavefronts transforms up to 16 frames of one clip.
+// The signal chunk (analysis) or the overlap-add buffer (synthesis) lives in LDS, so
+// every sample is read from / written to HBM once per kernel with 16-byte-coalesced
+// row accesses; the 75 % frame overlap is served from LDS.  Each wave runs the
+// 1024-point real FFT of fft512.hpp on one frame at a time.
+//
+// Reference operations replaced (all in /root/reference/src/AWARE):
+//   analysis  <- utils/audio/stft.py:27-28 (torch.stft, center/reflect, hann, onesided)
+//                + STFTDecomposer :54-55 (abs; the unit phasor S/|S| replaces angle)
+//                + WaveformNormalizer utils/audio/waveform.py:18-19 fused into the load
+//   synthesis <- STFTAssembler stft.py:61-62 (mag*exp(i phase), phasor precomputed)
+//                + ISTFT :47-48 (irfft, window, overlap-add, / envelope, trim)
+//   *_bwd     <- what torch autograd derives for the two above inside
+//                embedding/multibit_embedder.py:95-111, written out by hand; the
+//                NAdam + clamp + best-snapshot epilogue replaces :112-122.
+#include "common.hpp"
+#include "kernels.h"
+
+namespace aware {
+
+// ---------------------------------------------------------------------------------
+// |x| maximum per clip, as per-segment partials (4096 samples per workgroup)
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void absmax_partial_kernel(const float* __restrict__ sig,
+                                                                   const int* __restrict__ sig_off,
+                                                                   const int* __restrict__ sig_len,
+                                                                   unsigned long long* __restrict__ pmax,
+                                                                   int pstride) {
+    __shared__ unsigned long long red[4];
+    const int b = blockIdx.y;
+    const int n = sig_len[b];
+    const int s0 = blockIdx.x * 4096;
+    if (s0 >= n) return;
+    const float* x = sig + sig_off[b];
+    unsigned long long v = 0;
+    for (int i = s0 + threadIdx.x; i < min(n, s0 + 4096); i += kThreads) v = umax64(v, pack_max(fabsf(x[i]), i));
+    v = wave_max64(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) pmax[(size_t)b * pstride + blockIdx.x] = umax64(umax64(red[0], red[1]), umax64(red[2], red[3]));
+}
+
+// ---------------------------------------------------------------------------------
+// Analysis: frames -> windowed real FFT -> epilogue
+// ---------------------------------------------------------------------------------
+enum { AN_NORM = 0, AN_ADJ = 1 };
+
+struct AnalysisArgs {
+    PlanDev plan;
+    const int* frame_off;             // [B+1]
+    const float* sig;                 // signal base
+    const int* sig_off;               // [B] float offset of clip b in `sig`
+    const int* sig_len;               // [B] samples (reflect padding uses this length)
+    const unsigned long long* pmax;   // [B][pstride] partial |y| maxima (or null: no normalisation)
+    const int* pcount;                // [B] number of partials
+    int pstride;
+    int double_norm;                  // AN_NORM: 1 = y/m/m2, 0 = y/m
+    float unit_default;               // phasor written where |X| == 0 (x component)
+    float* mag;                       // [NF][kFS] or null
+    cf* unit;                         // [NF][kFS] or null
+    cf* full;                         // [NF][520] full complex spectrum (k = 0..512) or null
+    // AN_ADJ only (adjoint of synthesis + fused optimiser step)
+    const float* yraw;                // un-normalised synthesis output (same offsets as sig)
+    const double* pdot;               // [B][pstride] partial sums of g*y2
+    const cf* phasor;                 // [NF][kFS] unit phasor of the original phase
+    float* coef;                      // [NF][kFS] variables
+    float* mom;                       // exp_avg
+    float* vel;                       // exp_avg_sq
+    const float* lo;
+    const float* hi;
+    float* best;
+    const int* improved;              // [B]
+    const float4* sched;              // per step {c_grad, c_mom, bias_correction2, 0}
+    const int* step;                  // device step counter
+    float* grad_out;                  // optional [NF][kFS] raw gradient (tests)
+    int do_step;                      // 0: only write grad_out
+    float4 hyp;                       // {1-beta1, beta2, 1-beta2, eps}
+};
+
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void analysis_kernel(AnalysisArgs a) {
+    __shared__ float chunk[kChunk];
+    __shared__ cf scratch[4][kFftScratch];
+    __shared__ unsigned long long red[4];
+    __shared__ double dred[4];
+
+    const int b = blockIdx.y;
+    const int f0 = a.frame_off[b];
+    const int T = a.frame_off[b + 1] - f0;
+    const int t0 = blockIdx.x * kFramesPerWG;
+    if (t0 >= T) return;
+    const int nfr = min(kFramesPerWG, T - t0);
+    const int n = a.sig_len[b];
+    const float* x = a.sig + a.sig_off[b];
+    const int tid = threadIdx.x;
+
+    // ---- per-clip scalars -----------------------------------------------------------
+    float m = 1.f, m2 = 1.f;
+    unsigned kmax = 0xFFFFFFFFu;
+    if (a.pmax) {
+        ClipNorm cn = clip_norm_from_partials(a.pmax + (size_t)b * a.pstride, a.pcount[b], red);
+        m = cn.m;
+        m2 = (MODE == AN_ADJ || a.double_norm) ? cn.m2 : 1.f;
+        kmax = cn.k;
+    }
+    float adot = 0.f, smax = 0.f;
+    if (MODE == AN_ADJ) {
+        // A = sum_j g2[j]*y2[j] (fixed summation order) and the sign of the max sample
+        double s = 0.0;
+        const double* pd = a.pdot + (size_t)b * a.pstride;
+        for (int i = tid; i < a.pcount[b]; i += kThreads) s += pd[i];
+        s = wave_sum_d(s);
+        if ((tid & 63) == 0) dred[tid >> 6] = s;
+        __syncthreads();
+        adot = (float)(dred[0] + dred[1] + dred[2] + dred[3]);
+        float yk = a.yraw[a.sig_off[b] + kmax];
+        smax = (yk > 0.f) ? 1.f : ((yk < 0.f) ? -1.f : 0.f);
+    }
+
+    // ---- stage the signal chunk: padded positions [256*t0, 256*t0 + 256*(nfr-1)+1024) --
+    const int p0 = kHop * t0;
+    const int cnt = kHop * (nfr - 1) + kNfft;
+    for (int i = tid; i < cnt; i += kThreads) {
+        const int p = p0 + i;
+        int src = p - kHalf;
+        float v;
+        if (MODE == AN_NORM) {
+            if (src < 0) src = -src;
+            if (src >= n) src = 2 * (n - 1) - src;
+            v = x[src];
+            if (a.pmax) { v = v / m; if (a.double_norm) v = v / m2; }
+        } else {
+            // adjoint of (trim, / envelope): zero outside the kept region
+            if (src >= 0 && src < n) {
+                float g = x[src];
+                if ((unsigned)src == kmax) g -= adot * smax;
+                g = g / (m * m2);
+                v = g / ola_envelope(a.plan.window2, p, T);
+            } else {
+                v = 0.f;
+            }
+        }
+        chunk[i] = v;
+    }
+    __syncthreads();
+
+    // ---- per-wave FFTs ---------------------------------------------------------------
+    const int wave = tid >> 6, lane = tid & 63;
+    cf* s = scratch[wave];
+    FftLaneConst fc;
+    fft_lane_const(lane, a.plan.tw512, fc);
+    float wr[16];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        wr[2 * r] = a.plan.window[2 * (lane + 64 * r)];
+        wr[2 * r + 1] = a.plan.window[2 * (lane + 64 * r) + 1];
+    }
+    const int band_lo = a.plan.band_lo, nband = a.plan.nband;
+    float4 sc = make_float4(0.f, 0.f, 1.f, 0.f);
+    int improved = 0;
+    if (MODE == AN_ADJ && a.do_step) {
+        sc = a.sched[*a.step];
+        improved = a.improved[b];
+    }
+
+    for (int fr = wave; fr < nfr; fr += 4) {
+        cf v[8];
+        const float2* c2 = reinterpret_cast<const float2*>(chunk + kHop * fr);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            float2 q = c2[lane + 64 * r];
+            v[r] = mk(q.x * wr[2 * r], q.y * wr[2 * r + 1]);
+        }
+        fft512_wave<-1>(lane, v, fc, s);
+        rfft_split_store(lane, v, s);
+        wave_sync();
+        const size_t row = (size_t)(f0 + t0 + fr);
+        if (a.full) {
+            cf* out = a.full + row * 520;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) out[lane + 64 * r] = rfft_split_bin(lane + 64 * r, v[r], s, a.plan.tw1024);
+            if (lane == 0) out[512] = mk(rfft_split_nyquist(s), 0.f);
+        }
+        if (a.mag || a.unit || MODE == AN_ADJ) {
+            // band bins k = band_lo + f, f < nband (<= 256)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int k = lane + 64 * r;
+                const int f = k - band_lo;
+                if (f < 0 || f >= kFS) continue;
+                const size_t idx = row * kFS + f;
+                if (f >= nband) {
+                    if (MODE == AN_NORM) {
+                        if (a.mag) a.mag[idx] = 0.f;
+                        if (a.unit) a.unit[idx] = mk(0.f, 0.f);
+                    }
+                    continue;
+                }
+                cf X = rfft_split_bin(k, v[r], s, a.plan.tw1024);
+                if (MODE == AN_NORM) {
+                    float mg = sqrtf(X.x * X.x + X.y * X.y);
+                    if (a.mag) a.mag[idx] = mg;
+                    if (a.unit) a.unit[idx] = (mg > 0.f) ? mk(X.x / mg, X.y / mg) : mk(a.unit_default, 0.f);
+                } else {
+                    // dL/dc = Re(G conj P) with G = (2/N) rfft(.)  [adjoint of irfft on interior bins]
+                    cf P = a.phasor[idx];
+                    float g = (X.x * P.x + X.y * P.y) * (1.0f / 512.0f);
+                    if (a.grad_out) a.grad_out[idx] = g;
+                    if (a.do_step) {
+                        // torch.optim.NAdam single-tensor step + clamp + best snapshot
+                        float mo = a.mom[idx], ve = a.vel[idx], p = a.coef[idx];
+                        mo = mo + a.hyp.x * (g - mo);                    // exp_avg.lerp_(grad, 1-beta1)
+                        ve = ve * a.hyp.y + (a.hyp.z * g) * g;          // mul_(beta2).addcmul_(g, g, 1-beta2)
+                        float den = sqrtf(ve / sc.z) + a.hyp.w;
+                        p = p + (sc.x * g) / den;
+                        p = p + (sc.y * mo) / den;
+                        p = fminf(fmaxf(p, a.lo[idx]), a.hi[idx]);
+                        a.mom[idx] = mo; a.vel[idx] = ve; a.coef[idx] = p;
+                        if (improved) a.best[idx] = p;
+                    }
+                }
+            }
+        }
+        wave_sync();
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Synthesis: spectrum -> inverse real FFT -> window -> overlap-add -> epilogue
+// ---------------------------------------------------------------------------------
+enum { SY_FWD = 0, SY_ADJ = 1 };
+
+struct SynthArgs {
+    PlanDev plan;
+    const int* frame_off;
+    const float* amp;                 // [NF][kFS] real amplitude (coefficients or dL/dmag)
+    const cf* ph;                     // [NF][kFS] unit phasor
+    const cf* full;                   // [NF][520] full complex spectrum (SY_FWD only) or null
+    float* out;                       // per-clip signals at offset 256*(frame_off[b]-b)
+    const float* add;                 // SY_FWD: constant out-of-band part added to the output (or null)
+    unsigned long long* pmax;         // SY_FWD: [B][pstride] partial maxima out
+    int pstride;
+    // SY_ADJ
+    const float* yraw;                // forward synthesis output
+    const unsigned long long* pmax_in;
+    const int* pcount;
+    double* pdot;                     // [B][pstride] partial sums of g2*y2 out
+};
+
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void synth_kernel(SynthArgs a) {
+    __shared__ float ola[kChunk];
+    __shared__ cf scratch[4][kFftScratch];
+    __shared__ unsigned long long red[4];
+    __shared__ double dred[4];
+
+    const int b = blockIdx.y;
+    const int f0 = a.frame_off[b];
+    const int T = a.frame_off[b + 1] - f0;
+    const int nblk = T - 1;                     // output hop blocks
+    int nseg, jb0, jb1;
+    synth_segment(nblk, blockIdx.x, nseg, jb0, jb1);
+    if ((int)blockIdx.x >= nseg || T < 1) return;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+
+    // frames that touch the padded range this workgroup needs
+    int tlo = max(0, jb0 - 1);
+    int thi = min(T - 1, jb1 + 1);
+    if (MODE == SY_ADJ) {
+        if (blockIdx.x == 0) tlo = 0;
+        if ((int)blockIdx.x == nseg - 1) thi = T - 1;
+    }
+    const int nfr = thi - tlo + 1;              // <= 16 by construction
+    const int pbase = kHop * tlo;               // padded position of ola[0]
+
+    ClipNorm cn;
+    cn.m = 1.f; cn.m2 = 1.f; cn.k = 0;
+    if (MODE == SY_ADJ) cn = clip_norm_from_partials(a.pmax_in + (size_t)b * a.pstride, a.pcount[b], red);
+
+    for (int i = tid; i < kChunk; i += kThreads) ola[i] = 0.f;
+    __syncthreads();
+
+    cf* s = scratch[wave];
+    FftLaneConst fc;
+    fft_lane_const(lane, a.plan.tw512, fc);
+    float wr[16];
+    // irfft's 1/1024 (1/2 in the merge, 1/512 here); the adjoint of the forward rfft is 512*irfft
+    const float scale = (MODE == SY_FWD) ? (1.0f / 512.0f) : 1.0f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        wr[2 * r] = a.plan.window[2 * (lane + 64 * r)] * scale;
+        wr[2 * r + 1] = a.plan.window[2 * (lane + 64 * r) + 1] * scale;
+    }
+    const int band_lo = a.plan.band_lo, nband = a.plan.nband;
+
+    // 4 rounds; in round r wave w owns frame r + 4w: concurrently processed frames are
+    // 4 hops = 1024 samples apart, so the overlap-add needs no atomics and its
+    // summation order is fixed.
+    for (int r4 = 0; r4 < 4; ++r4) {
+        const int fi = r4 + 4 * wave;
+        if (fi < nfr) {
+            const size_t row = (size_t)(f0 + tlo + fi);
+            cf v[8];
+            if (MODE == SY_FWD && a.full) {
+                const cf* X = a.full + row * 520;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int k = lane + 64 * r;
+                    cf xk = X[k], xp = X[512 - k];
+                    if (k == 0) { xk.y = 0.f; xp.y = 0.f; }      // C2R ignores Im of DC / Nyquist
+                    v[r] = irfft_merge_bin(k, xk, xp, a.plan.tw1024);
+                }
+            } else {
+                const float* A = a.amp + row * kFS;
+                const cf* P = a.ph + row * kFS;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int k = lane + 64 * r;
+                    const int f = k - band_lo, fp = (512 - k) - band_lo;
+                    cf xk = mk(0.f, 0.f), xp = mk(0.f, 0.f);
+                    if (f >= 0 && f < nband) { float am = A[f]; cf p = P[f]; xk = mk(am * p.x, am * p.y); }
+                    if (fp >= 0 && fp < nband) { float am = A[fp]; cf p = P[fp]; xp = mk(am * p.x, am * p.y); }
+                    v[r] = irfft_merge_bin(k, xk, xp, a.plan.tw1024);
+                }
+            }
+            fft512_wave<1>(lane, v, fc, s);
+            float2* o2 = reinterpret_cast<float2*>(ola + kHop * fi);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                float2 q = o2[lane + 64 * r];
+                q.x += v[r].x * wr[2 * r];
+                q.y += v[r].y * wr[2 * r + 1];
+                o2[lane + 64 * r] = q;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- output pass ------------------------------------------------------------------
+    const int Ny = kHop * nblk;
+    float* out = a.out + sig_offset(a.frame_off, b);
+    const int j0 = kHop * jb0, j1 = kHop * jb1;
+    if (MODE == SY_FWD) {
+        const float* add = a.add ? a.add + sig_offset(a.frame_off, b) : nullptr;
+        unsigned long long best = 0;
+        for (int j = j0 + tid; j < j1; j += kThreads) {
+            const int p = kHalf + j;
+            float v = ola[p - pbase] / ola_envelope(a.plan.window2, p, T);
+            if (add) v += add[j];
+            out[j] = v;
+            best = umax64(best, pack_max(fabsf(v), (unsigned)j));
+        }
+        if (a.pmax) {
+            best = wave_max64(best);
+            if (lane == 0) red[wave] = best;
+            __syncthreads();
+            if (tid == 0) a.pmax[(size_t)b * a.pstride + blockIdx.x] = umax64(umax64(red[0], red[1]), umax64(red[2], red[3]));
+        }
+    } else {
+        // adjoint of reflect padding: fold the two 512-sample pads back, then the partial
+        // dot product with the normalised forward signal for the normaliser's backward
+        const float* y = a.yraw + sig_offset(a.frame_off, b);
+        double acc = 0.0;
+        for (int j = j0 + tid; j < j1; j += kThreads) {
+            float g = ola[kHalf + j - pbase];
+            if (j >= 1 && j <= kHalf) g += ola[kHalf - j - pbase];
+            if (j >= Ny - kHalf - 1 && j <= Ny - 2) g += ola[2 * Ny + kHalf - 2 - j - pbase];
+            out[j] = g;
+            float y2 = (y[j] / cn.m) / cn.m2;
+            acc += (double)g * (double)y2;
+        }
+        acc = wave_sum_d(acc);
+        if (lane == 0) dred[wave] = acc;
+        __syncthreads();
+        if (tid == 0) a.pdot[(size_t)b * a.pstride + blockIdx.x] = dred[0] + dred[1] + dred[2] + dred[3];
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// small elementwise kernels of the embed set-up / tear-down
+// ---------------------------------------------------------------------------------
+// bounds (multibit_embedder.py:157-160, :89-90) and optimiser state reset
+__global__ void embed_prepare_kernel(const float* __restrict__ c0, float* __restrict__ coef, float* __restrict__ lo,
+                                     float* __restrict__ hi, float* __restrict__ mom, float* __restrict__ vel,
+                                     float* __restrict__ best, float ratio, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float c = c0[i];
+    float d = c * ratio;
+    coef[i] = c;
+    lo[i] = fmaxf(c - d, 0.f);
+    hi[i] = c + d;
+    mom[i] = 0.f;
+    vel[i] = 0.f;
+    best[i] = c;
+}
+
+// y_oob[j] = x[j]/m - band[j]   (constant out-of-band part of the synthesis)
+__global__ void oob_residual_kernel(const float* __restrict__ audio, const int* __restrict__ in_off,
+                                    const unsigned long long* __restrict__ pmax, const int* __restrict__ pcount, int pstride,
+                                    const float* __restrict__ band, const int* __restrict__ frame_off, float* __restrict__ oob) {
+    __shared__ unsigned long long red[4];
+    const int b = blockIdx.y;
+    ClipNorm cn = clip_norm_from_partials(pmax + (size_t)b * pstride, pcount[b], red);
+    const int Ny = kHop * (frame_off[b + 1] - frame_off[b] - 1);
+    const int so = sig_offset(frame_off, b);
+    const float* x = audio + in_off[b];
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < Ny; j += gridDim.x * blockDim.x)
+        oob[so + j] = x[j] / cn.m - band[so + j];
+}
+
+// final waveform: normalise once and rescale by the caller's signed max
+// (multibit_embedder.py:185-194 + service/embed.py:69,73)
+__global__ void finish_kernel(const float* __restrict__ yraw, const int* __restrict__ frame_off,
+                              const unsigned long long* __restrict__ pmax, const int* __restrict__ pcount, int pstride,
+                              const float* __restrict__ rescale, float* __restrict__ out, const int* __restrict__ out_off) {
+    __shared__ unsigned long long red[4];
+    const int b = blockIdx.y;
+    ClipNorm cn = clip_norm_from_partials(pmax + (size_t)b * pstride, pcount[b], red);
+    const int Ny = kHop * (frame_off[b + 1] - frame_off[b] - 1);
+    const int so = sig_offset(frame_off, b);
+    const float r = rescale ? rescale[b] : 1.f;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < Ny; j += gridDim.x * blockDim.x)
+        out[out_off[b] + j] = r * (yraw[so + j] / cn.m);
+}
+
+// ---------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------
+static inline dim3 grid2(int x, int y) { return dim3((unsigned)x, (unsigned)y, 1); }
+
+void launch_absmax_partials(const float* sig, const int* sig_off, const int* sig_len, unsigned long long* pmax,
+                            int pstride, int B, int max_len, hipStream_t st) {
+    int nx = (max_len + 4095) / 4096;
+    hipLaunchKernelGGL(absmax_partial_kernel, grid2(nx, B), dim3(kThreads), 0, st, sig, sig_off, sig_len, pmax, pstride);
+}
+
+void launch_analysis(const AnalysisLaunch& L, hipStream_t st) {
+    AnalysisArgs a{};
+    a.plan = L.plan;
+    a.frame_off = L.frame_off;
+    a.sig = L.sig; a.sig_off = L.sig_off; a.sig_len = L.sig_len;
+    a.pmax = L.pmax; a.pcount = L.pcount; a.pstride = L.pstride;
+    a.double_norm = L.double_norm; a.unit_default = L.unit_default;
+    a.mag = L.mag; a.unit = (cf*)L.unit; a.full = (cf*)L.full;
+    a.yraw = L.yraw; a.pdot = L.pdot; a.phasor = (const cf*)L.phasor;
+    a.coef = L.coef; a.mom = L.mom; a.vel = L.vel; a.lo = L.lo; a.hi = L.hi; a.best = L.best;
+    a.improved = L.improved; a.sched = (const float4*)L.sched; a.step = L.step;
+    a.grad_out = L.grad_out; a.do_step = L.do_step;
+    a.hyp = make_float4(L.hyp[0], L.hyp[1], L.hyp[2], L.hyp[3]);
+    int nx = (L.max_frames + kFramesPerWG - 1) / kFramesPerWG;
+    if (L.adjoint)
+        hipLaunchKernelGGL(analysis_kernel<AN_ADJ>, grid2(nx, L.B), dim3(kThreads), 0, st, a);
+    else
+        hipLaunchKernelGGL(analysis_kernel<AN_NORM>, grid2(nx, L.B), dim3(kThreads), 0, st, a);
+}
+
+void launch_synth(const SynthLaunch& L, hipStream_t st) {
+    SynthArgs a{};
+    a.plan = L.plan;
+    a.frame_off = L.frame_off;
+    a.amp = L.amp; a.ph = (const cf*)L.ph; a.full = (const cf*)L.full;
+    a.out = L.out; a.add = L.add; a.pmax = L.pmax; a.pstride = L.pstride;
+    a.yraw = L.yraw; a.pmax_in = L.pmax_in; a.pcount = L.pcount; a.pdot = L.pdot;
+    int nblk = L.max_frames - 1;
+    int nx = (nblk + kSynthBlocks - 1) / kSynthBlocks;
+    if (nx < 1) nx = 1;
+    if (L.adjoint)
+        hipLaunchKernelGGL(synth_kernel<SY_ADJ>, grid2(nx, L.B), dim3(kThreads), 0, st, a);
+    else
+        hipLaunchKernelGGL(synth_kernel<SY_FWD>, grid2(nx, L.B), dim3(kThreads), 0, st, a);
+}
+
+void launch_embed_prepare(const float* c0, float* coef, float* lo, float* hi, float* mom, float* vel, float* best,
+                          float ratio, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(embed_prepare_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c0, coef, lo, hi, mom,
+                       vel, best, ratio, n);
+}
+
+void launch_oob_residual(const float* audio, const int* in_off, const unsigned long long* pmax, const int* pcount,
+                         int pstride, const float* band, const int* frame_off, float* oob, int B, int max_frames,
+                         hipStream_t st) {
+    int nx = max(1, (kHop * (max_frames - 1) + 1023) / 1024);
+    hipLaunchKernelGGL(oob_residual_kernel, grid2(nx, B), dim3(256), 0, st, audio, in_off, pmax, pcount, pstride, band,
+                       frame_off, oob);
+}
+
+void launch_finish(const float* yraw, const int* frame_off, const unsigned long long* pmax, const int* pcount,
+                   int pstride, const float* rescale, float* out, const int* out_off, int B, int max_frames,
+                   hipStream_t st) {
+    int nx = max(1, (kHop * (max_frames - 1) + 1023) / 1024);
+    hipLaunchKernelGGL(finish_kernel, grid2(nx, B), dim3(256), 0, st, yraw, frame_off, pmax, pcount, pstride, rescale,
+                       out, out_off);
+}
+
+}  // namespace aware

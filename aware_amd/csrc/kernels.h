@@ -1,0 +1,104 @@
+// Internal launch interface between the C ABI (capi.hip) and the kernel files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include "common.hpp"
+
+namespace aware {
+
+// ---- dsp_kernels.hip ------------------------------------------------------------------
+struct AnalysisLaunch {
+    PlanDev plan;
+    const int* frame_off = nullptr;
+    int B = 0, max_frames = 0;
+    const float* sig = nullptr;
+    const int* sig_off = nullptr;
+    const int* sig_len = nullptr;
+    const unsigned long long* pmax = nullptr;
+    const int* pcount = nullptr;
+    int pstride = 0;
+    int double_norm = 0;
+    float unit_default = 0.f;
+    float* mag = nullptr;
+    void* unit = nullptr;
+    void* full = nullptr;
+    // adjoint mode
+    int adjoint = 0;
+    const float* yraw = nullptr;
+    const double* pdot = nullptr;
+    const void* phasor = nullptr;
+    float* coef = nullptr; float* mom = nullptr; float* vel = nullptr;
+    const float* lo = nullptr; const float* hi = nullptr; float* best = nullptr;
+    const int* improved = nullptr;
+    const void* sched = nullptr;
+    const int* step = nullptr;
+    float* grad_out = nullptr;
+    int do_step = 0;
+    float hyp[4] = {0.1f, 0.999f, 0.001f, 1e-8f};
+};
+struct SynthLaunch {
+    PlanDev plan;
+    const int* frame_off = nullptr;
+    int B = 0, max_frames = 0;
+    const float* amp = nullptr;
+    const void* ph = nullptr;
+    const void* full = nullptr;
+    float* out = nullptr;
+    const float* add = nullptr;
+    unsigned long long* pmax = nullptr;
+    int pstride = 0;
+    int adjoint = 0;
+    const float* yraw = nullptr;
+    const unsigned long long* pmax_in = nullptr;
+    const int* pcount = nullptr;
+    double* pdot = nullptr;
+};
+void launch_absmax_partials(const float* sig, const int* sig_off, const int* sig_len, unsigned long long* pmax,
+                            int pstride, int B, int max_len, hipStream_t st);
+void launch_analysis(const AnalysisLaunch& L, hipStream_t st);
+void launch_synth(const SynthLaunch& L, hipStream_t st);
+void launch_embed_prepare(const float* c0, float* coef, float* lo, float* hi, float* mom, float* vel, float* best,
+                          float ratio, size_t n, hipStream_t st);
+void launch_oob_residual(const float* audio, const int* in_off, const unsigned long long* pmax, const int* pcount,
+                         int pstride, const float* band, const int* frame_off, float* oob, int B, int max_frames,
+                         hipStream_t st);
+void launch_finish(const float* yraw, const int* frame_off, const unsigned long long* pmax, const int* pcount,
+                   int pstride, const float* rescale, float* out, const int* out_off, int B, int max_frames,
+                   hipStream_t st);
+
+// ---- detector_kernels.hip ---------------------------------------------------------------
+// C[M][N] = A[M][K] * Bt[N][K]^T (+ bias[N]); all row-major fp32, K % 4 == 0, 16-byte aligned rows
+void launch_gemm_nt(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc, int M,
+                    int N, int K, hipStream_t st);
+// mel block: InstanceNorm over time, per-clip GlobalStandardize, AvgPool(2,2)
+void launch_mel_norm_fwd(const float* xm, const int* frame_off, const int* pool_off, float* x0, float* mu, float* rs,
+                         float* gstat, int B, hipStream_t st);
+void launch_mel_norm_bwd(const float* dx0, float* xm_inout, const int* frame_off, const int* pool_off, const float* mu,
+                         const float* rs, const float* gstat, int B, hipStream_t st);
+// conv block tail: InstanceNorm over time + LeakyReLU(0.2), in place; saves rstd
+void launch_in_lrelu_fwd(float* z, const int* pool_off, float* rstd, int C, int B, hipStream_t st);
+// backward of the same, in place on dA (A is the post-activation output of the forward)
+void launch_in_lrelu_bwd(float* dA, const float* A, const int* pool_off, const float* rstd, int C, int B,
+                         hipStream_t st);
+// BRH + loss + dL/dA3; also best-loss tracking
+void launch_head(const float* a3, const int* pool_off, const float* target, float* pred, float* loss,
+                 float* best_loss, int* improved, float* dA3, int* step, int loss_kind, int nbits, int B,
+                 hipStream_t st);
+void launch_advance_step(int* step, hipStream_t st);
+
+// ---- attack_kernels.hip -----------------------------------------------------------------
+void launch_pcm_quantize(const float* in, float* out, const int* off, const int* len, const unsigned long long* pmax,
+                         const int* pcount, int pstride, float q, float lo, float hi, int B, int max_len,
+                         hipStream_t st);
+void launch_upfirdn(const float* in, const int* in_off, const int* in_len, float* out, const int* out_off,
+                    const int* out_len, const float* h, int nh, int up, int down, int half_len, int B, int max_out,
+                    hipStream_t st);
+void launch_iir_full(const float* in, const int* off, const int* len, void* out, int out_f64, const double* b,
+                     const double* a, const double* zi, int ncoef, int mode, double* scratch, int sstride, int B,
+                     hipStream_t st);
+void launch_gaussian_noise_full(const float* in, float* out, const int* off, const int* len, const unsigned* seeds,
+                                double* power, float snr_db, int B, int max_len, hipStream_t st);
+void launch_segment_copy(const float* in, const int* in_off, float* out, const int* out_off, const int* out_len,
+                         const int* cut_start, const int* cut_len, int zero_fill, int B, int max_len, hipStream_t st);
+
+}  // namespace aware

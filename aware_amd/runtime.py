@@ -1,0 +1,275 @@
+"""Object wrappers over the C ABI: plan, batch geometry, detector weights, embed session.
+
+PyTorch-ROCm is used for device memory and streams only; every computation below is a
+call into libaware_hip.so on `torch.cuda.current_stream()`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import EmbedConfig, check, load_library, require_gpu
+
+SPEC_STRIDE = 256
+FULL_STRIDE = 520
+LOSS_KINDS = {"push_extremes": 0, "mse": 1, "hinge": 2, "sign": 3}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
+
+
+def _dev():
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class Plan:
+    """FFT tables + window + embedding band (aware_plan)."""
+
+    def __init__(self, n_fft=1024, hop=256, win_length=1024, window="hann", band_bins=(32, 256)):
+        require_gpu()
+        self.lib = load_library()
+        wid = {"hann": 0, "hamming": 1}.get(window)
+        if wid is None:
+            raise ValueError(f"Invalid window type: {window}")       # utils/audio/stft.py:25
+        h = C.c_void_p()
+        check(self.lib.aware_plan_create(C.byref(h), n_fft, hop, win_length, wid, int(band_bins[0]), int(band_bins[1])),
+              "aware_plan_create")
+        self.h = h
+        self.n_fft, self.hop, self.band_bins = n_fft, hop, (int(band_bins[0]), int(band_bins[1]))
+        self.nband = self.band_bins[1] - self.band_bins[0] + 1
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.aware_plan_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class Batch:
+    """Ragged batch geometry (aware_batch)."""
+
+    def __init__(self, lengths: Sequence[int], in_offsets: Sequence[int] | None = None):
+        require_gpu()
+        self.lib = load_library()
+        self.lengths = [int(x) for x in lengths]
+        self.B = len(self.lengths)
+        arr = (C.c_int * self.B)(*self.lengths)
+        if in_offsets is None:
+            self.in_offsets = np.concatenate([[0], np.cumsum(self.lengths)[:-1]]).astype(np.int64).tolist()
+            off = None
+        else:
+            self.in_offsets = [int(x) for x in in_offsets]
+            off = (C.c_int * self.B)(*self.in_offsets)
+        h = C.c_void_p()
+        rc = self.lib.aware_batch_create(C.byref(h), self.B, arr, off)
+        if rc == -1:
+            raise ValueError("every clip needs more than n_fft/2 = 512 samples")
+        check(rc, "aware_batch_create")
+        self.h = h
+        self.total_frames = self.lib.aware_batch_total_frames(h)
+        self.total_pooled = self.lib.aware_batch_total_pooled(h)
+        self.total_out = self.lib.aware_batch_total_out(h)
+        self.frames = [self.lib.aware_batch_frames(h, i) for i in range(self.B)]
+        self.out_offsets = [self.lib.aware_batch_out_offset(h, i) for i in range(self.B)]
+        self.out_lengths = [self.lib.aware_batch_out_length(h, i) for i in range(self.B)]
+        self.frame_offsets = np.concatenate([[0], np.cumsum(self.frames)]).tolist()
+        self.total_in = self.in_offsets[-1] + self.lengths[-1]
+        self.scratch_bytes = self.lib.aware_batch_scratch_bytes(h)
+        self.uniform = len(set(self.lengths)) == 1 and in_offsets is None
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.aware_batch_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def scratch(self):
+        return torch.empty(self.scratch_bytes, dtype=torch.uint8, device=_dev())
+
+    # ---- ragged <-> list helpers (plumbing) ----
+    def pack(self, clips) -> torch.Tensor:
+        """list of 1-D float arrays/tensors -> one device tensor laid out at in_offsets."""
+        out = torch.zeros(self.total_in, dtype=torch.float32, device=_dev())
+        for c, o, n in zip(clips, self.in_offsets, self.lengths):
+            out[o:o + n] = torch.as_tensor(c, dtype=torch.float32)
+        return out
+
+    def unpack_out(self, flat: torch.Tensor):
+        return [flat[o:o + n] for o, n in zip(self.out_offsets, self.out_lengths)]
+
+
+def stft(plan: Plan, batch: Batch, audio: torch.Tensor, normalize=False) -> torch.Tensor:
+    """Full one-sided spectrum, frame-major [total_frames, 520] complex64 (bins 0..512 valid)."""
+    spec = torch.empty((batch.total_frames, FULL_STRIDE), dtype=torch.complex64, device=audio.device)
+    scr = batch.scratch()
+    check(plan.lib.aware_stft(plan.h, batch.h, _ptr(audio), int(normalize), _ptr(spec), _ptr(scr), _stream()), "aware_stft")
+    return spec
+
+
+def istft(plan: Plan, batch: Batch, spec: torch.Tensor, normalize=False) -> torch.Tensor:
+    out = torch.empty(batch.total_out, dtype=torch.float32, device=spec.device)
+    scr = batch.scratch()
+    check(plan.lib.aware_istft(plan.h, batch.h, _ptr(spec), int(normalize), _ptr(out), _ptr(scr), _stream()), "aware_istft")
+    return out
+
+
+def stft_band(plan: Plan, batch: Batch, audio: torch.Tensor, normalize=True):
+    mag = torch.empty((batch.total_frames, SPEC_STRIDE), dtype=torch.float32, device=audio.device)
+    ph = torch.empty((batch.total_frames, SPEC_STRIDE), dtype=torch.complex64, device=audio.device)
+    scr = batch.scratch()
+    check(plan.lib.aware_stft_band(plan.h, batch.h, _ptr(audio), int(normalize), _ptr(mag), _ptr(ph), _ptr(scr), _stream()),
+          "aware_stft_band")
+    return mag, ph
+
+
+class DetectorWeights:
+    """Device copy of the frozen detector (aware_detector)."""
+
+    def __init__(self, plan: Plan, mel_basis: np.ndarray, weights, biases):
+        require_gpu()
+        self.lib = load_library()
+        self.plan = plan
+        mel = np.ascontiguousarray(mel_basis, dtype=np.float32)
+        ws = [np.ascontiguousarray(w, dtype=np.float32) for w in weights]
+        bs = [np.ascontiguousarray(b, dtype=np.float32) for b in biases]
+        chans = [ws[0].shape[1]] + [w.shape[0] for w in ws]
+        self.channels = chans
+        self.n_bits = chans[-1] // 2
+        nl = len(ws)
+        wp = (C.c_void_p * nl)(*[w.ctypes.data for w in ws])
+        bp = (C.c_void_p * nl)(*[b.ctypes.data for b in bs])
+        h = C.c_void_p()
+        rc = self.lib.aware_detector_create(C.byref(h), plan.h, C.c_void_p(mel.ctypes.data), mel.shape[0], nl,
+                                            (C.c_int * (nl + 1))(*chans), wp, bp)
+        check(rc, "aware_detector_create")
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.aware_detector_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def detect(plan: Plan, det: DetectorWeights, batch: Batch, audio: torch.Tensor) -> torch.Tensor:
+    """AWAREDetector.detect for a ragged batch -> [B, n_bits] raw values (device)."""
+    nbytes = plan.lib.aware_detect_workspace_bytes(batch.h, det.h)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=audio.device)
+    out = torch.empty((batch.B, det.n_bits), dtype=torch.float32, device=audio.device)
+    check(plan.lib.aware_detect(plan.h, det.h, batch.h, _ptr(audio), _ptr(out), _ptr(ws), nbytes, _stream()), "aware_detect")
+    return out
+
+
+def detector_forward(plan: Plan, det: DetectorWeights, batch: Batch, mag: torch.Tensor) -> torch.Tensor:
+    nbytes = plan.lib.aware_detect_workspace_bytes(batch.h, det.h)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=mag.device)
+    out = torch.empty((batch.B, det.n_bits), dtype=torch.float32, device=mag.device)
+    check(plan.lib.aware_detector_forward(det.h, batch.h, _ptr(mag), _ptr(out), _ptr(ws), nbytes, _stream()),
+          "aware_detector_forward")
+    return out
+
+
+class EmbedSession:
+    """One batched run of AWAREEmbedder._optimize (aware_embed)."""
+
+    def __init__(self, plan: Plan, det: DetectorWeights, batch: Batch, num_iterations=400, tolerance_db=6.0,
+                 loss="push_extremes", lr=0.1, beta1=0.9, beta2=0.999, eps=1e-8, momentum_decay=4e-3,
+                 use_graph=True):
+        self.lib = load_library()
+        self.plan, self.det, self.batch = plan, det, batch
+        if loss not in LOSS_KINDS:
+            raise ValueError(f"Unknown loss type: {loss}. Available on the HIP path: {list(LOSS_KINDS)}")
+        self.cfg = EmbedConfig(int(num_iterations), float(tolerance_db), LOSS_KINDS[loss], lr, beta1, beta2, eps,
+                               momentum_decay, int(bool(use_graph)))
+        self.nbytes = self.lib.aware_embed_workspace_bytes(batch.h, det.h)
+        self.ws = torch.empty(self.nbytes, dtype=torch.uint8, device=_dev())
+        h = C.c_void_p()
+        check(self.lib.aware_embed_create(C.byref(h), plan.h, det.h, batch.h, C.byref(self.cfg), _ptr(self.ws),
+                                          self.nbytes, _stream()), "aware_embed_create")
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.aware_embed_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def begin(self, audio: torch.Tensor, target: torch.Tensor):
+        self._audio, self._target = audio, target.contiguous().float()
+        check(self.lib.aware_embed_begin(self.h, _ptr(audio), _ptr(self._target), _stream()), "aware_embed_begin")
+
+    def iterate(self, n: int):
+        check(self.lib.aware_embed_iterate(self.h, int(n), _stream()), "aware_embed_iterate")
+
+    def gradient(self) -> torch.Tensor:
+        g = torch.zeros((self.batch.total_frames, SPEC_STRIDE), dtype=torch.float32, device=self.ws.device)
+        check(self.lib.aware_embed_gradient(self.h, _ptr(g), _stream()), "aware_embed_gradient")
+        return g
+
+    def finish(self, rescale: torch.Tensor | None = None) -> torch.Tensor:
+        out = torch.empty(self.batch.total_out, dtype=torch.float32, device=self.ws.device)
+        check(self.lib.aware_embed_finish(self.h, _ptr(rescale), _ptr(out), _stream()), "aware_embed_finish")
+        return out
+
+    def _view(self, which, shape, dtype=torch.float32):
+        p = self.lib.aware_embed_buffer(self.h, which)
+        n = int(np.prod(shape))
+        off = p - self.ws.data_ptr()
+        itemsize = torch.empty((), dtype=dtype).element_size()
+        return self.ws[off: off + n * itemsize].view(dtype).view(*shape)
+
+    @property
+    def loss(self):
+        return self._view(0, (self.batch.B,))
+
+    @property
+    def best_loss(self):
+        return self._view(1, (self.batch.B,))
+
+    @property
+    def pred(self):
+        return self._view(2, (self.batch.B, self.det.n_bits))
+
+    @property
+    def coef(self):
+        return self._view(3, (self.batch.total_frames, SPEC_STRIDE))
+
+    @property
+    def best_coef(self):
+        return self._view(4, (self.batch.total_frames, SPEC_STRIDE))
+
+    @property
+    def bounds(self):
+        return (self._view(5, (self.batch.total_frames, SPEC_STRIDE)),
+                self._view(6, (self.batch.total_frames, SPEC_STRIDE)))
+
+    @property
+    def step(self):
+        return self._view(8, (1,), torch.int32)
+
+
+def gemm_nt(a: torch.Tensor, bt: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
+    lib = load_library()
+    M, K = a.shape
+    N = bt.shape[0]
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    check(lib.aware_gemm_nt(_ptr(a), a.stride(0), _ptr(bt), bt.stride(0), _ptr(bias), _ptr(c), N, M, N, K, _stream()),
+          "aware_gemm_nt")
+    return c

@@ -1,0 +1,176 @@
+/* libaware_hip -- C ABI of the MI355X (gfx950) AWARE hot path.
+ *
+ * The drop-in boundary for deepmarkpy/aware's embed -> attack -> detect path.  The
+ * reference has no FFI of its own (it is pure Python); the seam it offers is the
+ * plugin call  BaseAudioProcessor.__call__(tensor) -> tensor
+ * (src/AWARE/interfaces/audio.py:6-9) plus AWAREEmbedder.embed / AWAREDetector.detect
+ * (src/AWARE/interfaces/embedding.py:5-8, interfaces/detection.py:6-14) and
+ * Attack.apply(audio, sr) (scripts/attacks.py:16-30).  Each entry point below names
+ * the reference code it replaces.  The host side (aware_amd/, Python + ctypes) maps
+ * these onto the reference's class / function names; see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer marked "dev" is a device (HBM) pointer owned by the caller
+ *     (PyTorch-ROCm tensors' data_ptr()); the library never frees caller memory;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     all work is enqueued on it, no entry point synchronises unless documented;
+ *   - return value: 0 on success, a negative AWARE_E_* code otherwise; nothing throws;
+ *   - all arithmetic is IEEE fp32 unless a parameter says f64;
+ *   - a "batch" is a ragged set of B mono clips; clip b has n_b samples,
+ *     T_b = 1 + n_b/256 frames, Ny_b = 256*(T_b-1) output samples, T_b/2 pooled frames.
+ *   - band-limited spectra are frame-major [total frames][256] (first 225 columns are
+ *     bins 32..256 = 500..4000 Hz at 16 kHz, n_fft 1024; the tail is zero).
+ */
+#ifndef AWARE_HIP_H
+#define AWARE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AWARE_OK 0
+#define AWARE_E_BADARG (-1)
+#define AWARE_E_UNSUPPORTED (-2)   /* e.g. n_fft != 1024, hop != 256, band wider than 256 bins */
+#define AWARE_E_HIP (-3)           /* a HIP runtime call failed; see aware_last_hip_error() */
+#define AWARE_E_WORKSPACE (-4)     /* caller's workspace too small */
+
+#define AWARE_SPEC_STRIDE 256      /* floats per frame row of a band-limited array */
+#define AWARE_FULL_STRIDE 520      /* complex values per frame row of a full one-sided spectrum */
+
+typedef struct aware_plan aware_plan;
+typedef struct aware_detector aware_detector;
+typedef struct aware_batch aware_batch;
+typedef struct aware_embed aware_embed;
+
+int aware_version(void);
+const char* aware_last_hip_error(void);
+
+/* ---- plan: FFT twiddles, window, band ------------------------------------------------
+ * Replaces the constructor state of STFT / ISTFT (src/AWARE/utils/audio/stft.py:14-25,
+ * :34-45: n_fft, hop_length, window "hann"|"hamming", win_length) and
+ * AWAREEmbedder._get_embedding_frequency_indices (embedding/multibit_embedder.py:43-47).
+ * window: 0 = hann (periodic), 1 = hamming (periodic).  band_lo_bin/band_hi_bin inclusive. */
+int aware_plan_create(aware_plan** out, int n_fft, int hop, int win_length, int window,
+                      int band_lo_bin, int band_hi_bin);
+void aware_plan_destroy(aware_plan* plan);
+
+/* ---- batch geometry ----------------------------------------------------------------------
+ * n_samples[B] (host): clip lengths.  in_offsets[B] (host, may be NULL = densely packed):
+ * float offset of clip b inside the caller's ragged audio array. */
+int aware_batch_create(aware_batch** out, int B, const int* n_samples, const int* in_offsets);
+void aware_batch_destroy(aware_batch* batch);
+int aware_batch_total_frames(const aware_batch* batch);   /* sum T_b          */
+int aware_batch_total_pooled(const aware_batch* batch);   /* sum T_b/2        */
+int aware_batch_total_out(const aware_batch* batch);      /* sum 256*(T_b-1)  */
+int aware_batch_out_offset(const aware_batch* batch, int b); /* float offset of clip b's output */
+int aware_batch_out_length(const aware_batch* batch, int b);
+int aware_batch_frames(const aware_batch* batch, int b);
+
+/* ---- DSP plug-ins ---------------------------------------------------------------------------
+ * aware_stft: WaveformNormalizer (optional) + STFT.__call__  (utils/audio/waveform.py:18-19,
+ * utils/audio/stft.py:27-28).  audio: dev ragged f32.  spec: dev complex64
+ * [total frames][AWARE_FULL_STRIDE] (bins 0..512 valid).  normalize: 0 none, 1 x/max(|x|+1e-8).
+ * scratch: dev, >= aware_batch_scratch_bytes(). */
+size_t aware_batch_scratch_bytes(const aware_batch* batch);
+int aware_stft(const aware_plan* plan, const aware_batch* batch, const float* audio, int normalize,
+               void* spec, void* scratch, void* stream);
+/* aware_istft: ISTFT.__call__ (utils/audio/stft.py:47-48; no length argument, output
+ * 256*(T-1) samples per clip at aware_batch_out_offset).  normalize as above, applied to the output. */
+int aware_istft(const aware_plan* plan, const aware_batch* batch, const void* spec, int normalize,
+                float* out, void* scratch, void* stream);
+/* aware_stft_band: normalise + STFT + STFTDecomposer restricted to the embedding band:
+ * mag [total frames][256] and unit phasor (cos, sin of the phase) [total frames][256] complex64. */
+int aware_stft_band(const aware_plan* plan, const aware_batch* batch, const float* audio, int normalize,
+                    float* mag, void* phasor, void* scratch, void* stream);
+
+/* ---- detector --------------------------------------------------------------------------------
+ * AWAREDetectorNet (detection/multibit_detector_net.py:17-80).  All arrays are host fp32:
+ * mel_basis [n_mels][n_fft/2+1] (detection/modules/mel.py:105-149), conv weights
+ * [channels[i+1]][channels[i]] and biases [channels[i+1]] for i < n_layers
+ * (channels = {128, 512, 1024, 1024, 40}).  The library uploads and pre-transposes them. */
+int aware_detector_create(aware_detector** out, const aware_plan* plan, const float* mel_basis, int n_mels,
+                          int n_layers, const int* channels, const float* const* weights,
+                          const float* const* biases);
+void aware_detector_destroy(aware_detector* det);
+
+/* AWAREDetector.detect (detection/multibit_detector.py:28-42), batched: normalise, STFT, |.|,
+ * zero the out-of-band bins, network forward.  values: dev f32 [B][n_bits].
+ * workspace: dev, >= aware_detect_workspace_bytes(). */
+size_t aware_detect_workspace_bytes(const aware_batch* batch, const aware_detector* det);
+int aware_detect(const aware_plan* plan, const aware_detector* det, const aware_batch* batch,
+                 const float* audio, float* values, void* workspace, size_t workspace_bytes, void* stream);
+/* network forward only (AWAREDetectorNet.forward, :109-140) on a band magnitude array */
+int aware_detector_forward(const aware_detector* det, const aware_batch* batch, const float* mag,
+                           float* values, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- embedder -----------------------------------------------------------------------------------
+ * AWAREEmbedder.embed / _optimize (embedding/multibit_embedder.py:70-197), batched and ragged:
+ * every clip is its own optimisation problem.  loss: 0 push_extremes, 1 mse, 2 hinge, 3 sign
+ * (embedding/losses.py:95-103).  optimizer: NAdam (embedding/optimizers.py:5; torch.optim.NAdam
+ * single-tensor semantics) with lr, beta1, beta2, eps, momentum_decay; the reference's
+ * ReduceLROnPlateau(patience 500) never fires within 400 iterations and is not modelled. */
+typedef struct aware_embed_config {
+    int num_iterations;      /* cards/config.yaml:16  (400) */
+    float tolerance_db;      /* cards/config.yaml:13  (6.0) */
+    int loss;                /* 0 = push_extremes */
+    float lr, beta1, beta2, eps, momentum_decay;   /* 0.1, 0.9, 0.999, 1e-8, 4e-3 */
+    int use_graph;           /* 1: capture one iteration into a hipGraph and replay it */
+} aware_embed_config;
+
+size_t aware_embed_workspace_bytes(const aware_batch* batch, const aware_detector* det);
+int aware_embed_create(aware_embed** out, const aware_plan* plan, const aware_detector* det,
+                       const aware_batch* batch, const aware_embed_config* cfg, void* workspace,
+                       size_t workspace_bytes, void* stream);
+void aware_embed_destroy(aware_embed* e);
+/* analysis, bounds, optimiser reset.  audio: dev ragged f32 (un-normalised); target: dev f32
+ * [B][n_bits] bipolar (+-1), PatternEncoder output (utils/watermark/encoder.py:35-45). */
+int aware_embed_begin(aware_embed* e, const float* audio, const float* target, void* stream);
+/* n_iters loop bodies (:95-122): synth -> normalise -> analysis -> detector fwd -> loss ->
+ * backward -> NAdam -> clamp -> best snapshot.  No host synchronisation. */
+int aware_embed_iterate(aware_embed* e, int n_iters, void* stream);
+/* forward + backward without the optimiser step; grad: dev f32 [total frames][256] = dL/dcoef */
+int aware_embed_gradient(aware_embed* e, float* grad, void* stream);
+/* final synthesis from the best coefficients (:173-194) and the service-level rescale
+ * (service/embed.py:69,73): out[b] = rescale[b] * normalise(istft(...)).  rescale: dev f32 [B] or NULL. */
+int aware_embed_finish(aware_embed* e, const float* rescale, float* out, void* stream);
+/* device pointers to internal state for inspection: 0 loss[B], 1 best_loss[B], 2 pred[B][n_bits],
+ * 3 coef [frames][256], 4 best coef, 5 lo, 6 hi, 7 phasor (complex64), 8 step counter (int32) */
+void* aware_embed_buffer(aware_embed* e, int which);
+
+/* ---- attacks (scripts/attacks.py) ------------------------------------------------------------------
+ * All operate on ragged batches given by dev int32 arrays off[B], len[B]. */
+/* PCMBitDepthConversion.apply :44-70. bits in {8,12,16,24}.  scratch >= B*ceil(max_len/4096)*8 bytes */
+int aware_pcm_quantize(const float* in, float* out, const int* off, const int* len, int B, int max_len,
+                       int bits, void* scratch, void* stream);
+/* scipy.signal.resample_poly's polyphase core (Resample.apply :290-293, scripts/test.py:60-63):
+ * out[j] = sum_i in[i] * h[j*down - i*up + half_len], fp32.  h: dev f32 [nh] (already scaled by up). */
+int aware_upfirdn(const float* in, const int* in_off, const int* in_len, float* out, const int* out_off,
+                  const int* out_len, int B, int max_out, const float* h, int nh, int up, int down,
+                  int half_len, void* stream);
+/* scipy.signal.lfilter (LowPassFilter / HighPassFilter :400-455) and filtfilt (RandomBandstop
+ * :324-356) in f64.  b, a: dev f64 [B][ncoef] (a[0] == 1); zi: dev f64 [B][ncoef-1] (filtfilt only).
+ * out is f64 when out_f64 != 0 (the reference returns float64 from lfilter), else f32.
+ * scratch (filtfilt): dev f64 [B][max_len + 6*ncoef]. */
+int aware_iir(const float* in, const int* off, const int* len, int B, int max_len, void* out, int out_f64,
+              const double* b, const double* a, const double* zi, int ncoef, int filtfilt,
+              void* scratch, void* stream);
+/* DeleteSamples :162-178 / Cropout :192-205 (zero_fill = 0) and SampleSupression :370-385
+ * (zero_fill = 1): cut_start[B], cut_len[B] dev int32 chosen by the host RNG. */
+int aware_segment_cut(const float* in, const int* in_off, float* out, const int* out_off, const int* out_len,
+                      const int* cut_start, const int* cut_len, int zero_fill, int B, int max_len, void* stream);
+/* EXTENSION (not in the reference): additive Gaussian noise at snr_db, Philox-4x32-10 keyed by
+ * seeds[b].  scratch >= B*8 bytes. */
+int aware_gaussian_noise(const float* in, float* out, const int* off, const int* len, int B, int max_len,
+                         const uint32_t* seeds, float snr_db, void* scratch, void* stream);
+
+/* ---- bare GEMM (tests / roofline): C[M][N] = A[M][K] * Bt[N][K]^T + bias ------------------------------ */
+int aware_gemm_nt(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc,
+                  int M, int N, int K, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AWARE_HIP_H */

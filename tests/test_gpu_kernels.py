@@ -1,0 +1,219 @@
+"""GPU parity tests of the HIP kernels (through the C ABI) against the CPU oracle.
+
+Run on the MI355X box:  python -m pytest tests -m gpu -x -q
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import make_clip, GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rt():
+    from aware_amd import runtime
+    from aware_amd._lib import require_gpu
+    require_gpu()
+    return runtime
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import aware_oracle
+    return aware_oracle
+
+
+@pytest.fixture(scope="module")
+def plan(rt):
+    return rt.Plan()
+
+
+@pytest.fixture(scope="module")
+def det(rt, plan, O):
+    ws, bs = O.detector_weights()
+    return rt.DetectorWeights(plan, O.mel_filter_bank(), [w.numpy() for w in ws], [b.numpy() for b in bs])
+
+
+def clips(seeds, n):
+    a = [make_clip(s, n) for s in seeds]
+    return [x[0] for x in a], np.stack([x[1] for x in a])
+
+
+@pytest.mark.parametrize("M,N,K", [(6016, 512, 128), (6016, 1024, 512), (1000, 40, 1024), (777, 1024, 40),
+                                   (12032, 128, 256), (300, 256, 128), (128, 128, 32), (130, 72, 36)])
+def test_gemm_nt(rt, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(N, K, generator=g)
+    bias = torch.randn(N, generator=g)
+    ref = (a.double() @ b.double().T + bias.double())
+    out = rt.gemm_nt(a.cuda(), b.cuda(), bias.cuda()).cpu()
+    err = (out.double() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err < 2e-6 * scale * max(1.0, K / 256), (err, scale)
+    out2 = rt.gemm_nt(a.cuda(), b.cuda(), None).cpu()
+    assert (out2.double() - (ref - bias.double())).abs().max().item() < 2e-6 * scale * max(1.0, K / 256)
+
+
+@pytest.mark.parametrize("lengths", [[48000], [16000, 48000, 20000], [48000] * 5, [16000 + 37, 513 + 256 * 14, 160000]])
+def test_stft_istft_vs_oracle(rt, plan, O, lengths):
+    """BASELINE config 2: STFT parity <= 1e-5 relative, round trip <= 2e-6 abs (unit-peak audio)."""
+    cl = [make_clip(10 + i, n)[0] for i, n in enumerate(lengths)]
+    batch = rt.Batch(lengths)
+    audio = batch.pack(cl)
+    spec = rt.stft(plan, batch, audio, normalize=True)
+    torch.cuda.synchronize()
+    spec_c = spec.cpu()
+    for i, c in enumerate(cl):
+        x = O.waveform_normalize(torch.from_numpy(c))
+        S = O.stft(x)                                    # [513, T]
+        T = S.shape[1]
+        assert T == batch.frames[i]
+        mine = spec_c[batch.frame_offsets[i]: batch.frame_offsets[i] + T, :513].T
+        err = (mine - S).abs().max().item()
+        assert err < 1e-5 * S.abs().max().item(), (i, err)
+    y = rt.istft(plan, batch, spec, normalize=False)
+    torch.cuda.synchronize()
+    for i, c in enumerate(cl):
+        x = O.waveform_normalize(torch.from_numpy(c))
+        mine = y[batch.out_offsets[i]: batch.out_offsets[i] + batch.out_lengths[i]].cpu()
+        ref = O.istft(O.stft(x))
+        assert mine.shape == ref.shape
+        assert (mine - ref).abs().max().item() < 2e-6
+        assert (mine - x[: mine.shape[0]]).abs().max().item() < 2e-6      # round trip
+    yn = rt.istft(plan, batch, spec, normalize=True).cpu()
+    for i in range(len(cl)):
+        seg = yn[batch.out_offsets[i]: batch.out_offsets[i] + batch.out_lengths[i]]
+        assert abs(seg.abs().max().item() - 1.0) < 1e-6
+
+
+def test_stft_band(rt, plan, O):
+    lengths = [48000, 16000]
+    cl = [make_clip(3 + i, n)[0] for i, n in enumerate(lengths)]
+    batch = rt.Batch(lengths)
+    mag, ph = rt.stft_band(plan, batch, batch.pack(cl), normalize=True)
+    mag, ph = mag.cpu(), ph.cpu()
+    for i, c in enumerate(cl):
+        S = O.stft(O.waveform_normalize(torch.from_numpy(c)))[32:257]       # [225, T]
+        sl = slice(batch.frame_offsets[i], batch.frame_offsets[i + 1])
+        assert (mag[sl, :225].T - S.abs()).abs().max().item() < 1e-5 * S.abs().max().item()
+        assert mag[sl, 225:].abs().max().item() == 0.0
+        assert ((mag[sl, :225] * ph[sl, :225]).T - S).abs().max().item() < 1e-5 * S.abs().max().item()
+
+
+def test_detector_forward_and_detect(rt, plan, det, O):
+    lengths = [48000, 16000, 30000]
+    cl = [make_clip(20 + i, n)[0] for i, n in enumerate(lengths)]
+    batch = rt.Batch(lengths)
+    vals = rt.detect(plan, det, batch, batch.pack(cl)).cpu().numpy()
+    emb = O.Embedder()
+    for i, c in enumerate(cl):
+        ref = emb.detect_raw(c[None])[0].numpy()
+        np.testing.assert_allclose(vals[i], ref, atol=5e-5)
+    # golden: the reference's own raw outputs for the unmarked seed clips
+    for tag, seed, n in (("1s", 1, 16000), ("3s", 0, 48000)):
+        e = np.load(os.path.join(GOLDEN, f"embed_{tag}.npz"))
+        a, _ = make_clip(seed, n)
+        b1 = rt.Batch([n])
+        v = rt.detect(plan, det, b1, b1.pack([a])).cpu().numpy()[0]
+        np.testing.assert_allclose(v, e["raw_unmarked"], atol=5e-5)
+
+
+@pytest.mark.parametrize("lengths,seeds", [([16000], [1]), ([48000, 16000, 23456], [0, 1, 2])])
+def test_first_iteration_gradient(rt, plan, det, O, lengths, seeds):
+    """dL/dcoef of the first loop body vs torch autograd on the oracle (and the reference's
+    own gradient for the golden seeds)."""
+    pairs = [make_clip(s, n) for s, n in zip(seeds, lengths)]
+    cl = [p[0] for p in pairs]
+    wm = np.stack([O.bits_to_bipolar(p[1]) for p in pairs]).astype(np.float32)
+    batch = rt.Batch(lengths)
+    sess = rt.EmbedSession(plan, det, batch, use_graph=False)
+    sess.begin(batch.pack(cl), torch.from_numpy(wm).cuda())
+    g = sess.gradient()
+    torch.cuda.synchronize()
+    g = g.cpu()
+    loss = sess.loss.cpu().numpy()
+    pred = sess.pred.cpu().numpy()
+    emb = O.Embedder()
+    for i, c in enumerate(cl):
+        a = torch.from_numpy(c)[None]
+        mag0, phase = emb.analyse(a)
+        c0 = mag0[:, emb.band].clone().requires_grad_(True)
+        l, p = emb.forward_loss(c0, mag0, phase, torch.from_numpy(wm[i])[None])
+        l.sum().backward()
+        ref = c0.grad[0]                                                    # [225, T]
+        mine = g[batch.frame_offsets[i]: batch.frame_offsets[i + 1], :225].T
+        assert abs(loss[i] - float(l)) < 2e-5, (loss[i], float(l))
+        np.testing.assert_allclose(pred[i], p[0].detach().numpy(), atol=5e-5)
+        rel = (mine - ref).norm().item() / ref.norm().item()
+        assert rel < 2e-3, rel
+    if seeds[0] == 1 and lengths[0] == 16000:
+        e = np.load(os.path.join(GOLDEN, "embed_1s.npz"))
+        mine = g[: batch.frames[0], :225].T.numpy()
+        ref = e["iter1_grad_sample"]
+        rel = np.linalg.norm(mine - ref) / np.linalg.norm(ref)
+        assert rel < 3e-3, rel
+        assert abs(loss[0] - float(e["iter1_loss"])) < 2e-5
+
+
+def test_embed_short_trajectory(rt, plan, det, O):
+    """20 optimiser steps: per-step losses track the oracle's (fp32 drift allowed)."""
+    lengths = [16000, 16000 + 256 * 7]
+    pairs = [make_clip(s, n) for s, n in zip([1, 5], lengths)]
+    cl = [p[0] for p in pairs]
+    wm = np.stack([O.bits_to_bipolar(p[1]) for p in pairs]).astype(np.float32)
+    batch = rt.Batch(lengths)
+    sess = rt.EmbedSession(plan, det, batch, num_iterations=20, use_graph=False)
+    sess.begin(batch.pack(cl), torch.from_numpy(wm).cuda())
+    mine = []
+    for it in range(20):
+        sess.iterate(1)
+        mine.append(sess.loss.cpu().numpy().copy())
+    mine = np.stack(mine)                    # [20, B]
+    for i, c in enumerate(cl):
+        emb = O.Embedder(num_iterations=20)
+        ref = []
+        emb.embed(c[None], wm[i][None], record=lambda it, l, p, g: ref.append(float(l[0])))
+        ref = np.asarray(ref)
+        assert abs(mine[0, i] - ref[0]) < 2e-5
+        assert np.max(np.abs(mine[:, i] - ref)) < 2e-2, (mine[:, i], ref)
+    assert int(sess.step.cpu()[0]) == 20
+
+
+def test_embed_full_1s_bits_exact(rt, plan, det, O):
+    """Full 400-iteration embed of the golden 1 s clip, graph replay on: the detected 20 bits
+    are exact, the trajectory is within the stated band of the reference's."""
+    e = np.load(os.path.join(GOLDEN, "embed_1s.npz"))
+    audio, bits = make_clip(1, 16000)
+    wm = O.bits_to_bipolar(bits).astype(np.float32)[None]
+    batch = rt.Batch([16000])
+    sess = rt.EmbedSession(plan, det, batch, use_graph=True)
+    a = batch.pack([audio])
+    sess.begin(a, torch.from_numpy(wm).cuda())
+    sess.iterate(400)
+    rescale = torch.tensor([float(np.max(audio))], device="cuda")
+    out = sess.finish(rescale)
+    torch.cuda.synchronize()
+    best = float(sess.best_loss.cpu()[0])
+    assert abs(best - float(e["losses"].min())) < 2e-2, best
+    out_c = out.cpu().numpy()
+    assert out_c.shape[0] == int(e["out_len"])
+    assert abs(out_c.max() - float(e["out_max"])) < 1e-6
+    ob = rt.Batch([out_c.shape[0]])
+    vals = rt.detect(plan, det, ob, out).cpu().numpy()[0]
+    det_bits = O.decode_bits(vals)
+    np.testing.assert_array_equal(det_bits, bits)
+    np.testing.assert_array_equal(det_bits, e["det_bits"])
+    assert np.min(np.abs(vals)) > 0.2
+    # the oracle (CPU) reads the same bits from the HIP-embedded audio
+    b2, raw2 = O.detect_watermark(out_c, O.Embedder())
+    np.testing.assert_array_equal(b2, bits)
+    np.testing.assert_allclose(raw2, vals, atol=1e-4)
+    # imperceptibility box: best coefficients stay inside [lo, hi]
+    lo, hi = sess.bounds
+    bc = sess.best_coef
+    assert bool(((bc >= lo) & (bc <= hi)).all())
