@@ -77,10 +77,12 @@ SIGNATURES = {
     "aware_embed_destroy": (None, [_vp]),
     "aware_embed_begin": (_i, [_vp, _vp, _vp, _vp]),
     "aware_embed_iterate": (_i, [_vp, _i, _vp]),
+    "aware_embed_profile": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "aware_embed_gradient": (_i, [_vp, _vp, _vp]),
     "aware_embed_finish": (_i, [_vp, _vp, _vp, _vp]),
     "aware_embed_buffer": (_vp, [_vp, _i]),
     "aware_pcm_quantize": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "aware_waveform_normalize": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "aware_upfirdn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp]),
     "aware_iir": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "aware_segment_cut": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -35,6 +35,20 @@ __global__ __launch_bounds__(256) void pcm_quantize_kernel(const float* __restri
     }
 }
 
+// WaveformNormalizer as a stand-alone op: x / max(|x| + 1e-8)  (utils/audio/waveform.py:18-19)
+__global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                         const int* __restrict__ off, const int* __restrict__ len,
+                                                         const unsigned long long* __restrict__ pmax,
+                                                         const int* __restrict__ pcount, int pstride) {
+    __shared__ unsigned long long red[4];
+    const int b = blockIdx.y;
+    ClipNorm cn = clip_norm_from_partials(pmax + (size_t)b * pstride, pcount[b], red);
+    const int n = len[b];
+    const float* x = in + off[b];
+    float* y = out + off[b];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) y[i] = x[i] / cn.m;
+}
+
 // y[j] = sum_i x[i] * h[j*down - i*up + half_len], float32, x ascending (scipy upfirdn order)
 __global__ __launch_bounds__(256) void upfirdn_kernel(const float* __restrict__ in, const int* __restrict__ in_off,
                                                        const int* __restrict__ in_len, float* __restrict__ out,
@@ -190,6 +204,10 @@ void launch_pcm_quantize(const float* in, float* out, const int* off, const int*
                          hipStream_t st) {
     hipLaunchKernelGGL(pcm_quantize_kernel, dim3(gx(max_len), B), dim3(256), 0, st, in, out, off, len, pmax, pcount,
                        pstride, q, lo, hi);
+}
+void launch_normalize(const float* in, float* out, const int* off, const int* len, const unsigned long long* pmax,
+                      const int* pcount, int pstride, int B, int max_len, hipStream_t st) {
+    hipLaunchKernelGGL(normalize_kernel, dim3(gx(max_len), B), dim3(256), 0, st, in, out, off, len, pmax, pcount, pstride);
 }
 void launch_upfirdn(const float* in, const int* in_off, const int* in_len, float* out, const int* out_off,
                     const int* out_len, const float* h, int nh, int up, int down, int half_len, int B, int max_out,

@@ -27,6 +27,30 @@ static thread_local std::string g_last_err;
     } while (0)
 #define LAUNCHCHK() HIPCHK(hipGetLastError())
 
+// Optional per-launch timing of one optimiser iteration (aware_embed_profile): an event is
+// recorded on the launch stream after every kernel; consecutive events bracket one kernel.
+struct LaunchProfiler {
+    hipStream_t st;
+    std::vector<hipEvent_t> ev;
+    std::vector<int> kind;
+};
+static thread_local LaunchProfiler* g_prof = nullptr;
+static inline void prof_mark(int kind) {
+    if (!g_prof) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, g_prof->st);
+    g_prof->ev.push_back(e);
+    g_prof->kind.push_back(kind);
+}
+#define PROF(kind) prof_mark(kind)
+// kernel kinds reported by aware_embed_profile
+enum { K_SYNTH = 0, K_ANALYSIS = 1, K_GEMM = 2, K_MELNORM = 3, K_INLRELU = 4, K_HEAD = 5, K_SYNTH_ADJ = 6,
+       K_ANALYSIS_ADJ = 7, K_MISC = 8 };
+
+static int absmax_into_scratch(const float* in, const int* off, const int* len, int B, int max_len, void* scratch,
+                               unsigned long long** pmax_out, int** pcount_out, int* ps_out, hipStream_t st);
+
 // ---------------------------------------------------------------------------------------------
 struct aware_plan {
     PlanDev dev;
@@ -345,16 +369,16 @@ static size_t det_bytes(const aware_batch* b, const aware_detector* d) {
 // forward through the network; mag [NF][256] -> act[last], pred
 static int det_forward(const aware_detector* d, const aware_batch* b, const float* mag, DetBufs& o, hipStream_t st) {
     launch_gemm_nt(mag, kFS, d->melT, kFS, nullptr, o.xm, 128, b->NF, 128, kFS, st);
-    LAUNCHCHK();
+    LAUNCHCHK(); PROF(K_GEMM);
     launch_mel_norm_fwd(o.xm, b->d_frame_off, b->d_pool_off, o.x0, o.mu, o.rs, o.gstat, b->B, st);
-    LAUNCHCHK();
+    LAUNCHCHK(); PROF(K_MELNORM);
     const float* x = o.x0;
     for (int l = 0; l < d->n_layers; ++l) {
         const int ci = d->ch[l], co = d->ch[l + 1];
         launch_gemm_nt(x, ci, d->w[l], ci, d->bias[l], o.act[l], co, b->NP, co, ci, st);
-        LAUNCHCHK();
+        LAUNCHCHK(); PROF(K_GEMM);
         launch_in_lrelu_fwd(o.act[l], b->d_pool_off, o.rstd[l], co, b->B, st);
-        LAUNCHCHK();
+        LAUNCHCHK(); PROF(K_INLRELU);
         x = o.act[l];
     }
     return AWARE_OK;
@@ -543,10 +567,8 @@ extern "C" int aware_embed_begin(aware_embed* e, const float* audio, const float
     LAUNCHCHK();
     HIPCHK(hipMemcpyAsync(e->target, target, (size_t)b->B * e->det->nbits * sizeof(float), hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemsetAsync(e->step, 0, 4 * sizeof(int), st));
-    // best_loss = +inf
-    std::vector<float> inf(b->B, INFINITY);
-    HIPCHK(hipMemcpyAsync(e->best_loss, inf.data(), b->B * sizeof(float), hipMemcpyHostToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));
+    // best_loss = +inf (0x7F800000)
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)e->best_loss, 0x7F800000, b->B, st));
     return AWARE_OK;
 }
 
@@ -560,7 +582,7 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
     S.plan = e->plan->dev; S.frame_off = b->d_frame_off; S.B = b->B; S.max_frames = b->max_frames;
     S.amp = e->coef; S.ph = e->P; S.out = e->yraw; S.add = e->oob; S.pmax = e->pmaxY; S.pstride = b->pstride;
     launch_synth(S, st);
-    LAUNCHCHK();
+    LAUNCHCHK(); PROF(K_SYNTH);
     // normalise x2 + STFT + |.| on the band (:104 zeroes the rest, so it is never computed)
     AnalysisLaunch L;
     L.plan = e->plan->dev; L.frame_off = b->d_frame_off; L.B = b->B; L.max_frames = b->max_frames;
@@ -568,7 +590,7 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
     L.pmax = e->pmaxY; L.pcount = b->d_pc_syn; L.pstride = b->pstride; L.double_norm = 1;
     L.mag = e->mag; L.unit = e->U; L.unit_default = 0.f;
     launch_analysis(L, st);
-    LAUNCHCHK();
+    LAUNCHCHK(); PROF(K_ANALYSIS);
     // :107 detector forward
     int rc = det_forward(d, b, e->mag, e->db, st);
     if (rc) return rc;
@@ -577,27 +599,27 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
     float* dB = e->d2;
     launch_head(e->db.act[nl - 1], b->d_pool_off, e->target, e->db.pred, e->loss, e->best_loss, e->improved, dA, e->step,
                 e->cfg.loss, d->nbits, b->B, st);
-    LAUNCHCHK();
+    LAUNCHCHK(); PROF(K_HEAD);
     // :111 backward through the detector (data gradients only; weights are frozen :76-77)
     for (int l = nl - 1; l >= 0; --l) {
         const int ci = d->ch[l], co = d->ch[l + 1];
         launch_in_lrelu_bwd(dA, e->db.act[l], b->d_pool_off, e->db.rstd[l], co, b->B, st);
-        LAUNCHCHK();
+        LAUNCHCHK(); PROF(K_INLRELU);
         launch_gemm_nt(dA, co, d->wT[l], co, nullptr, dB, ci, b->NP, ci, co, st);
-        LAUNCHCHK();
+        LAUNCHCHK(); PROF(K_GEMM);
         float* t = dA; dA = dB; dB = t;
     }
     launch_mel_norm_bwd(dA, e->db.xm, b->d_frame_off, b->d_pool_off, e->db.mu, e->db.rs, e->db.gstat, b->B, st);
-    LAUNCHCHK();
+    LAUNCHCHK(); PROF(K_MELNORM);
     launch_gemm_nt(e->db.xm, 128, d->melB, 128, nullptr, e->gmag, kFS, b->NF, kFS, 128, st);
-    LAUNCHCHK();
+    LAUNCHCHK(); PROF(K_GEMM);
     // backward through |.|, STFT, reflect padding
     SynthLaunch SA;
     SA.plan = e->plan->dev; SA.frame_off = b->d_frame_off; SA.B = b->B; SA.max_frames = b->max_frames;
     SA.amp = e->gmag; SA.ph = e->U; SA.out = e->gy; SA.adjoint = 1; SA.yraw = e->yraw; SA.pmax_in = e->pmaxY;
     SA.pcount = b->d_pc_syn; SA.pdot = e->pdot; SA.pstride = b->pstride;
     launch_synth(SA, st);
-    LAUNCHCHK();
+    LAUNCHCHK(); PROF(K_SYNTH_ADJ);
     // backward through the normalisers, ISTFT and the assembler; :112-117 NAdam + clamp
     AnalysisLaunch LA;
     LA.plan = e->plan->dev; LA.frame_off = b->d_frame_off; LA.B = b->B; LA.max_frames = b->max_frames;
@@ -608,10 +630,10 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
     LA.improved = e->improved; LA.sched = e->sched; LA.step = e->step; LA.grad_out = grad_out; LA.do_step = do_step;
     memcpy(LA.hyp, e->hyp, sizeof(LA.hyp));
     launch_analysis(LA, st);
-    LAUNCHCHK();
+    LAUNCHCHK(); PROF(K_ANALYSIS_ADJ);
     if (do_step) {
         launch_advance_step(e->step, st);
-        LAUNCHCHK();
+        LAUNCHCHK(); PROF(K_MISC);
     }
     return AWARE_OK;
 }
@@ -639,6 +661,30 @@ extern "C" int aware_embed_iterate(aware_embed* e, int n_iters, void* stream) {
     }
     for (int i = 0; i < n_iters; ++i) HIPCHK(hipGraphLaunch(e->gexec, st));
     return AWARE_OK;
+}
+
+extern "C" int aware_embed_profile(aware_embed* e, int n_iters, int max_entries, float* ms_out, int* kind_out,
+                                   void* stream) {
+    if (!e || !ms_out || !kind_out || n_iters < 1) return AWARE_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    LaunchProfiler p;
+    p.st = st;
+    g_prof = &p;
+    prof_mark(-1);
+    int rc = AWARE_OK;
+    for (int i = 0; i < n_iters && rc == AWARE_OK; ++i) rc = embed_iteration(e, st, 1, nullptr);
+    g_prof = nullptr;
+    hipError_t se = hipStreamSynchronize(st);
+    int n = 0;
+    for (size_t i = 1; i < p.ev.size(); ++i) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, p.ev[i - 1], p.ev[i]);
+        if (n < max_entries) { ms_out[n] = ms; kind_out[n] = p.kind[i]; ++n; }
+    }
+    for (auto& ev : p.ev) (void)hipEventDestroy(ev);
+    if (rc) return rc;
+    HIPCHK(se);
+    return n;      // number of entries written (>= 0)
 }
 
 extern "C" int aware_embed_gradient(aware_embed* e, float* grad, void* stream) {
@@ -674,19 +720,36 @@ extern "C" int aware_pcm_quantize(const float* in, float* out, const int* off, c
         default: return AWARE_E_BADARG;   // reference raises ValueError
     }
     hipStream_t st = (hipStream_t)stream;
+    unsigned long long* pmax; int* pcount; int ps;
+    int rc = absmax_into_scratch(in, off, len, B, max_len, scratch, &pmax, &pcount, &ps, st);
+    if (rc) return rc;
+    launch_pcm_quantize(in, out, off, len, pmax, pcount, ps, q, lo, hi, B, max_len, st);
+    LAUNCHCHK();
+    return AWARE_OK;
+}
+
+// shared by the max-abs normalising entry points: partial maxima + counts in `scratch`
+static int absmax_into_scratch(const float* in, const int* off, const int* len, int B, int max_len, void* scratch,
+                               unsigned long long** pmax_out, int** pcount_out, int* ps_out, hipStream_t st) {
     const int ps = (max_len + 4095) / 4096;
     unsigned long long* pmax = (unsigned long long*)scratch;
     int* pcount = (int*)(pmax + (size_t)B * ps);
-    // pcount[b] = ceil(len/4096): computed on device by a tiny kernel would need another launch;
-    // the caller's `len` is a device array, so derive the counts with the partial kernel's own rule
-    // by zero-filling the partials first (a zero partial never wins the max).
     HIPCHK(hipMemsetAsync(pmax, 0, (size_t)B * ps * sizeof(unsigned long long), st));
     launch_absmax_partials(in, off, len, pmax, ps, B, max_len, st);
     LAUNCHCHK();
-    std::vector<int> pc(B, ps);
-    HIPCHK(hipMemcpyAsync(pcount, pc.data(), B * sizeof(int), hipMemcpyHostToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));
-    launch_pcm_quantize(in, out, off, len, pmax, pcount, ps, q, lo, hi, B, max_len, st);
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)pcount, ps, B, st));
+    *pmax_out = pmax; *pcount_out = pcount; *ps_out = ps;
+    return AWARE_OK;
+}
+
+extern "C" int aware_waveform_normalize(const float* in, float* out, const int* off, const int* len, int B,
+                                        int max_len, void* scratch, void* stream) {
+    if (!in || !out || !off || !len || !scratch || B < 1) return AWARE_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long* pmax; int* pcount; int ps;
+    int rc = absmax_into_scratch(in, off, len, B, max_len, scratch, &pmax, &pcount, &ps, st);
+    if (rc) return rc;
+    launch_normalize(in, out, off, len, pmax, pcount, ps, B, max_len, st);
     LAUNCHCHK();
     return AWARE_OK;
 }

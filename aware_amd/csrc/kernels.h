@@ -90,6 +90,8 @@ void launch_advance_step(int* step, hipStream_t st);
 void launch_pcm_quantize(const float* in, float* out, const int* off, const int* len, const unsigned long long* pmax,
                          const int* pcount, int pstride, float q, float lo, float hi, int B, int max_len,
                          hipStream_t st);
+void launch_normalize(const float* in, float* out, const int* off, const int* len, const unsigned long long* pmax,
+                      const int* pcount, int pstride, int B, int max_len, hipStream_t st);
 void launch_upfirdn(const float* in, const int* in_off, const int* in_len, float* out, const int* out_off,
                     const int* out_len, const float* h, int nh, int up, int down, int half_len, int B, int max_out,
                     hipStream_t st);

@@ -1,0 +1,66 @@
+"""Loss registry of the embedder (reference: src/AWARE/embedding/losses.py:95-118).
+
+On the HIP path the loss, its gradient and the best-loss bookkeeping are evaluated per clip
+inside the read-out kernel (csrc/detector_kernels.hip: head_kernel); the classes here carry the
+name -> kernel id mapping and a host-side forward for inspection."""
+import torch
+
+from ..interfaces import Loss
+
+
+class _KernelLoss(Loss):
+    kernel_id = None
+    name = None
+
+    def __init__(self, **kwargs):
+        if kwargs:
+            # the reference forwards kwargs to the class (penalty_weight for push_extremes)
+            if self.name == "push_extremes" and set(kwargs) == {"penalty_weight"} and kwargs["penalty_weight"] == 0.1:
+                return
+            raise NotImplementedError(f"loss {self.name}: non-default parameters {kwargs} are not on the HIP path")
+
+
+class PushToExtremesLoss(_KernelLoss):
+    """mse - 0.1 * mean|pred|  (losses.py:38-42)"""
+    kernel_id, name = 0, "push_extremes"
+
+    def forward(self, predicted, target_pattern):
+        return torch.mean((predicted - target_pattern) ** 2) - 0.1 * torch.mean(torch.abs(predicted))
+
+
+class MSELoss(_KernelLoss):
+    """losses.py:23-25"""
+    kernel_id, name = 1, "mse"
+
+    def forward(self, predicted, target_pattern):
+        return torch.mean((predicted - target_pattern) ** 2)
+
+
+class HingeLoss(_KernelLoss):
+    """losses.py:12-14"""
+    kernel_id, name = 2, "hinge"
+
+    def forward(self, predicted, target_pattern):
+        return torch.mean(torch.clamp(1 - predicted * target_pattern, min=0))
+
+
+class SignBasedLoss(_KernelLoss):
+    """losses.py:68-70"""
+    kernel_id, name = 3, "sign"
+
+    def forward(self, predicted, target_pattern):
+        return torch.mean(torch.clamp(-predicted * target_pattern, min=0))
+
+
+registry = {"hinge": HingeLoss, "mse": MSELoss, "push_extremes": PushToExtremesLoss, "sign": SignBasedLoss}
+# names the reference registers for sigmoid-output / non-differentiable variants (losses.py:99-102);
+# its own detector ends in tanh, so they are not part of the hot path
+_NOT_ON_HIP = ("push_sigmoid", "bce", "ber")
+
+
+def get_loss_fn(loss_type: str, **kwargs) -> Loss:
+    if loss_type in _NOT_ON_HIP:
+        raise NotImplementedError(f"loss '{loss_type}' is registered by the reference but not implemented on the HIP path")
+    if loss_type not in registry:
+        raise ValueError(f"Unknown loss type: {loss_type}. Available: {list(registry.keys()) + list(_NOT_ON_HIP)}")
+    return registry[loss_type](**kwargs)

@@ -1,0 +1,100 @@
+"""AWAREEmbedder: per-clip adversarial optimisation of the in-band STFT magnitudes against the
+frozen detector, batched over clips on the GPU.
+
+Reference: src/AWARE/embedding/multibit_embedder.py:17-197.  embed() keeps the reference's
+signature and return value (normalised waveform of 256*(T-1) samples); embed_batch() is the
+MI355X entry point: any number of ragged clips, one optimisation problem each, all iterations
+enqueued without host synchronisation."""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import torch
+
+from ..detection import AWAREDetectorNet
+from ..interfaces import BaseEmbedder
+from ..utils.audio import ISTFT, STFT, STFTAssembler, STFTDecomposer, WaveformNormalizer, band_bins, get_plan
+from ..utils.logger import logger
+from .. import runtime as rt
+from .losses import get_loss_fn
+from .optimizers import get_optimizer
+from .schedulers import get_scheduler
+
+
+class AWAREEmbedder(BaseEmbedder):
+    def __init__(self, frame_length: int = 1024, hop_length: int = 256, window: str = "hann", win_length: int = 1024,
+                 pattern_mode: str = "bits2bipolar", embedding_bands=(500, 4000), tolerance_db: float = 6.0,
+                 num_iterations: int = 400, detection_net_cfg: dict = None, optimizer_cfg: dict = None,
+                 scheduler_cfg: dict = None, loss: str = "push", verbose: bool = True, use_graph: bool = True):
+        self.frame_length, self.hop_length, self.window, self.win_length = frame_length, hop_length, window, win_length
+        self.device = torch.device("cuda")
+        self.embedding_bands = tuple(embedding_bands)
+        self.tolerance_db = tolerance_db
+        self.num_iterations = num_iterations
+        self.pattern_mode = pattern_mode
+        self.detection_net = AWAREDetectorNet(**(detection_net_cfg or {}))
+        optimizer_cfg = optimizer_cfg or {"name": "nadam", "params": {"lr": 0.1}}
+        scheduler_cfg = scheduler_cfg or {"name": "reduce_lr_on_plateau", "params": {"factor": 0.9, "patience": 500}}
+        self.optimizer_name, self.optimizer_params = optimizer_cfg["name"], optimizer_cfg.get("params", {}) or {}
+        self.scheduler_name, self.scheduler_params = scheduler_cfg["name"], scheduler_cfg.get("params", {}) or {}
+        self.loss = get_loss_fn(loss)                     # ValueError on an unknown name, as the reference
+        self._opt = get_optimizer(self.optimizer_name, None, **self.optimizer_params)
+        self._sched = get_scheduler(self.scheduler_name, num_iterations, **self.scheduler_params)
+        self.verbose = verbose
+        self.use_graph = use_graph
+        self.audio_preprocess_pipeline = [WaveformNormalizer(), STFT(frame_length, hop_length, window, win_length), STFTDecomposer()]
+        self.audio_postprocess_pipeline = [STFTAssembler(), ISTFT(frame_length, hop_length, window, win_length), WaveformNormalizer()]
+
+    # ---- geometry ---------------------------------------------------------------------------
+    def _get_embedding_frequency_indices(self, sampling_rate: int, frame_length: int):
+        lo, hi = band_bins(sampling_rate, frame_length, self.embedding_bands)
+        allb = np.arange(1 + frame_length // 2)
+        mask = (allb >= lo) & (allb <= hi)
+        return allb[mask], allb[~mask]
+
+    def _plan(self, sample_rate):
+        return get_plan(self.frame_length, self.hop_length, self.window,
+                        band_bins(sample_rate, self.frame_length, self.embedding_bands))
+
+    # ---- batched hot path ----------------------------------------------------------------------
+    def start_session(self, batch: "rt.Batch", sample_rate: int) -> "rt.EmbedSession":
+        plan = self._plan(sample_rate)
+        b1, b2 = self._opt["betas"]
+        return rt.EmbedSession(plan, self.detection_net.device_weights(plan), batch,
+                               num_iterations=self.num_iterations, tolerance_db=self.tolerance_db,
+                               loss=self.loss.name, lr=self._opt["lr"], beta1=b1, beta2=b2, eps=self._opt["eps"],
+                               momentum_decay=self._opt["momentum_decay"], use_graph=self.use_graph)
+
+    def embed_device(self, audio: torch.Tensor, batch: "rt.Batch", sample_rate: int, watermarks: torch.Tensor,
+                     rescale: torch.Tensor | None = None, session: "rt.EmbedSession" = None):
+        """audio: device f32 ragged at batch.in_offsets; watermarks: device [B, n_bits] bipolar.
+        Returns (flat device output at batch.out_offsets, session)."""
+        sess = session or self.start_session(batch, sample_rate)
+        sess.begin(audio, watermarks)
+        sess.iterate(self.num_iterations)
+        return sess.finish(rescale), sess
+
+    def embed_batch(self, clips, sample_rate: int, watermarks, rescale=None):
+        """clips: list of 1-D float arrays; watermarks: [B, n_bits] bipolar.  Returns a list of
+        device tensors (one per clip, length 256*(T_b-1))."""
+        t0 = time.time()
+        batch = rt.Batch([len(c) for c in clips])
+        wm = torch.as_tensor(np.asarray(watermarks), dtype=torch.float32, device="cuda")
+        rs = None if rescale is None else torch.as_tensor(np.asarray(rescale), dtype=torch.float32, device="cuda")
+        out, sess = self.embed_device(batch.pack(clips), batch, sample_rate, wm, rs)
+        if self.verbose:
+            torch.cuda.synchronize()
+            logger.info(f"Optimization completed in {time.time() - t0:.1f}s after {self.num_iterations} iterations")
+            logger.info(f"Final loss: {float(sess.best_loss.mean()):.6f}")
+        return batch.unpack_out(out)
+
+    # ---- reference-shaped single-clip entry ------------------------------------------------------
+    def embed(self, audio: np.ndarray, sample_rate: int, watermark: np.ndarray) -> np.ndarray:
+        try:
+            out = self.embed_batch([np.asarray(audio, dtype=np.float32)], sample_rate,
+                                   np.asarray(watermark, dtype=np.float32)[None])
+        except Exception as exc:
+            logger.error(f"Error during embedding: {exc}")
+            raise
+        return out[0].detach().cpu().numpy()

@@ -1,0 +1,64 @@
+"""Data parallelism over clips: one process per GPU, no collective on the data path.
+
+Every clip is an independent optimisation problem against a detector that each rank regenerates
+bit-identically from the seed (reference: service/embed.py:52-53 runs even the two stereo channels
+as separate problems; multibit_detector_net.py:78 fixes the seed), so ranks only exchange the
+final counters: bit errors, bits, waveform-seconds (SUM) and wall time (MAX).  torch.distributed's
+"nccl" backend is RCCL on ROCm; "gloo" is used on CPU-only hosts (tests)."""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed():
+    """(rank, world_size, local_rank) from the torchrun environment; initialises the process
+    group when WORLD_SIZE > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+    return rank, world, local_rank
+
+
+def shard_by_cost(costs, world: int):
+    """Longest-processing-time assignment of clips to ranks: cost is proportional to the frame
+    count T.  Returns a list of index lists, one per rank; deterministic."""
+    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+    loads = [0.0] * world
+    shards = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (loads[k], k))
+        shards[r].append(i)
+        loads[r] += costs[i]
+    for s in shards:
+        s.sort()
+    return shards
+
+
+def reduce_metrics(sums: dict, maxes: dict, device=None):
+    """All-reduce a handful of scalars: `sums` with SUM, `maxes` with MAX.  No-op for one rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return dict(sums), dict(maxes)
+    device = device or (torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else "cpu")
+    ks, km = sorted(sums), sorted(maxes)
+    ts = torch.tensor([float(sums[k]) for k in ks], dtype=torch.float64, device=device)
+    tm = torch.tensor([float(maxes[k]) for k in km], dtype=torch.float64, device=device)
+    dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+    dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    return {k: float(v) for k, v in zip(ks, ts.tolist())}, {k: float(v) for k, v in zip(km, tm.tolist())}
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

@@ -1,0 +1,105 @@
+"""Batched embed -> attack -> detect driver: the loop of the reference's harness
+(/root/reference/scripts/test.py:52-106) with every stage resident on the GPU.
+
+One call processes a ragged batch of clips: optional 44.1 kHz -> 16 kHz polyphase front end
+(scripts/test.py:60-63), embed (400 iterations per clip), the attack stage, detect, BER."""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import runtime as rt
+from .attacks import resample_poly_batch
+
+
+@dataclass
+class PipelineResult:
+    bits: torch.Tensor                    # [B, n_bits] detected bits after the attack stage (device, int32)
+    values: torch.Tensor                  # [B, n_bits] raw detector outputs
+    bit_errors: torch.Tensor              # scalar tensor: number of wrong bits
+    clean_bit_errors: torch.Tensor        # scalar tensor: wrong bits without any attack
+    watermarked: "rt.Ragged" = None
+    per_attack_errors: dict = field(default_factory=dict)
+    seconds: float = 0.0                  # waveform-seconds processed (at the input rate)
+
+
+class WatermarkPipeline:
+    def __init__(self, embedder, detector, attacks=(), sample_rate: int = 16000, attack_mode: str = "chain"):
+        if attack_mode not in ("chain", "each"):
+            raise ValueError("attack_mode must be 'chain' or 'each'")
+        self.embedder, self.detector = embedder, detector
+        self.attacks = list(attacks)
+        self.sample_rate = sample_rate
+        self.attack_mode = attack_mode
+        self._sessions = {}
+
+    @staticmethod
+    def _clip_max(x: "rt.Ragged") -> torch.Tensor:
+        """signed per-clip maximum (service/embed.py:69)"""
+        if len(set(x.lengths)) == 1:
+            return x.data.view(x.B, -1).amax(dim=1)
+        return torch.segment_reduce(x.data, "max", lengths=x.d_len.long())
+
+    def _detect_bits(self, x: "rt.Ragged"):
+        data = x.data if x.data.dtype == torch.float32 else x.data.float()
+        key = ("det",) + tuple(x.lengths)
+        if key not in self._sessions:
+            self._sessions[key] = rt.Batch(x.lengths)
+        vals = self.detector.detect_device(data, self._sessions[key], self.sample_rate)
+        return (vals > self.detector.threshold).to(torch.int32), vals
+
+    def run(self, audio: "rt.Ragged", bits: torch.Tensor, input_rate: int | None = None) -> PipelineResult:
+        """audio: ragged device clips at `input_rate` (default: the pipeline's 16 kHz);
+        bits: device int tensor [B, n_bits] of 0/1."""
+        input_rate = input_rate or self.sample_rate
+        seconds = float(sum(audio.lengths)) / float(input_rate)
+        x = audio
+        if input_rate != self.sample_rate:
+            x = resample_poly_batch(audio, self.sample_rate, input_rate)            # scripts/test.py:60-63
+        key = tuple(x.lengths)
+        if key not in self._sessions:          # geometry tables + workspace are reused across steps
+            b = rt.Batch(x.lengths)
+            self._sessions[key] = (b, self.embedder.start_session(b, self.sample_rate))
+        batch, sess = self._sessions[key]
+        target = (2 * bits - 1).to(torch.float32)                                  # PatternEncoder bits2bipolar
+        out, _ = self.embedder.embed_device(x.data, batch, self.sample_rate, target, self._clip_max(x), session=sess)
+        wm = rt.Ragged(out, batch.out_lengths)
+        clean_bits, clean_vals = self._detect_bits(wm)
+        clean_err = (clean_bits != bits).sum()
+        per = {}
+        if not self.attacks:
+            return PipelineResult(clean_bits, clean_vals, clean_err, clean_err, wm, per, seconds)
+        if self.attack_mode == "chain":
+            y = wm
+            for a in self.attacks:
+                if y.data.dtype != torch.float32:
+                    y = rt.Ragged(y.data.float(), y.lengths)
+                y = a.apply_batch(y, self.sample_rate)
+            det_bits, vals = self._detect_bits(y)
+            err = (det_bits != bits).sum()
+            per["+".join(a.name for a in self.attacks)] = err
+            return PipelineResult(det_bits, vals, err, clean_err, wm, per, seconds)
+        total = torch.zeros((), dtype=torch.int64, device=bits.device)
+        det_bits, vals = clean_bits, clean_vals
+        for a in self.attacks:
+            y = a.apply_batch(wm, self.sample_rate)
+            det_bits, vals = self._detect_bits(y)
+            e = (det_bits != bits).sum()
+            per[a.name] = e
+            total = total + e
+        return PipelineResult(det_bits, vals, total, clean_err, wm, per, seconds)
+
+
+def synthetic_clips(n_clips: int, seconds: float, rate: int, first_seed: int = 0, device="cuda"):
+    """Synthetic workload of BASELINE.json: sigma = 0.1 Gaussian clips, 20 random bits per clip,
+    generated on the device from the clip's global index (so every rank draws its own shard)."""
+    n = int(round(seconds * rate))
+    audio = torch.empty((n_clips, n), dtype=torch.float32, device=device)
+    bits = torch.empty((n_clips, 20), dtype=torch.int32, device=device)
+    for i in range(n_clips):
+        g = torch.Generator(device=device).manual_seed(1_000_003 * (first_seed + i) + 17)
+        audio[i] = 0.1 * torch.randn(n, generator=g, device=device)
+        bits[i] = torch.randint(0, 2, (20,), generator=g, device=device, dtype=torch.int32)
+    return rt.Ragged(audio.reshape(-1), [n] * n_clips), bits

@@ -273,3 +273,124 @@ def gemm_nt(a: torch.Tensor, bt: torch.Tensor, bias: torch.Tensor | None = None)
     check(lib.aware_gemm_nt(_ptr(a), a.stride(0), _ptr(bt), bt.stride(0), _ptr(bias), _ptr(c), N, M, N, K, _stream()),
           "aware_gemm_nt")
     return c
+
+
+# ---------------------------------------------------------------------------------------------
+# ragged signal batches and the attack-stage entry points
+# ---------------------------------------------------------------------------------------------
+class Ragged:
+    """B mono clips packed back to back in one device tensor (plumbing for the attack stage)."""
+
+    def __init__(self, data: torch.Tensor, lengths: Sequence[int]):
+        self.data = data
+        self.lengths = [int(n) for n in lengths]
+        self.offsets = np.concatenate([[0], np.cumsum(self.lengths)[:-1]]).astype(np.int64).tolist()
+        self.B = len(self.lengths)
+        self.max_len = max(self.lengths)
+        dev = data.device
+        self.d_off = torch.tensor(self.offsets, dtype=torch.int32, device=dev)
+        self.d_len = torch.tensor(self.lengths, dtype=torch.int32, device=dev)
+
+    @classmethod
+    def from_list(cls, clips, dtype=torch.float32):
+        lengths = [len(c) for c in clips]
+        data = torch.cat([torch.as_tensor(np.asarray(c), dtype=dtype) for c in clips]).to(_dev())
+        return cls(data, lengths)
+
+    def like(self, dtype=None):
+        return Ragged(torch.empty_like(self.data, dtype=dtype or self.data.dtype), self.lengths)
+
+    def to_list(self):
+        flat = self.data.detach().cpu().numpy()
+        return [flat[o:o + n] for o, n in zip(self.offsets, self.lengths)]
+
+    def batch(self) -> Batch:
+        return Batch(self.lengths)
+
+    def _scratch(self):
+        ps = (self.max_len + 4095) // 4096
+        return torch.empty(self.B * (ps * 8 + 8) + 64, dtype=torch.uint8, device=self.data.device)
+
+
+def waveform_normalize(x: Ragged) -> Ragged:
+    lib = load_library()
+    out = x.like()
+    scr = x._scratch()
+    check(lib.aware_waveform_normalize(_ptr(x.data), _ptr(out.data), _ptr(x.d_off), _ptr(x.d_len), x.B, x.max_len,
+                                       _ptr(scr), _stream()), "aware_waveform_normalize")
+    return out
+
+
+def pcm_quantize(x: Ragged, bits: int) -> Ragged:
+    lib = load_library()
+    out = x.like()
+    scr = x._scratch()
+    rc = lib.aware_pcm_quantize(_ptr(x.data), _ptr(out.data), _ptr(x.d_off), _ptr(x.d_len), x.B, x.max_len, int(bits),
+                                _ptr(scr), _stream())
+    if rc == -1:
+        raise ValueError(f"Unsupported PCM bit depth: {bits}")            # scripts/attacks.py:69
+    check(rc, "aware_pcm_quantize")
+    return out
+
+
+def upfirdn(x: Ragged, h: torch.Tensor, up: int, down: int, half_len: int) -> Ragged:
+    """polyphase resampler core; output length ceil(n*up/down) per clip (scipy.resample_poly)."""
+    lib = load_library()
+    out_len = [-(-n * up // down) for n in x.lengths]
+    out = Ragged(torch.empty(sum(out_len), dtype=torch.float32, device=x.data.device), out_len)
+    check(lib.aware_upfirdn(_ptr(x.data), _ptr(x.d_off), _ptr(x.d_len), _ptr(out.data), _ptr(out.d_off), _ptr(out.d_len),
+                            x.B, out.max_len, _ptr(h), h.numel(), up, down, half_len, _stream()), "aware_upfirdn")
+    return out
+
+
+def iir(x: Ragged, b: np.ndarray, a: np.ndarray, zi: np.ndarray | None = None, filtfilt=False, out_f64=False) -> Ragged:
+    """b, a: [B, ncoef] float64 (a[:,0] == 1) per clip; zi [B, ncoef-1] for filtfilt."""
+    lib = load_library()
+    dev = x.data.device
+    bd = torch.as_tensor(np.ascontiguousarray(b, dtype=np.float64), device=dev)
+    ad = torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=dev)
+    ncoef = bd.shape[1]
+    zd = None if zi is None else torch.as_tensor(np.ascontiguousarray(zi, dtype=np.float64), device=dev)
+    out = x.like(torch.float64 if out_f64 else torch.float32)
+    scr = torch.empty(x.B * (x.max_len + 6 * ncoef), dtype=torch.float64, device=dev) if filtfilt else None
+    check(lib.aware_iir(_ptr(x.data), _ptr(x.d_off), _ptr(x.d_len), x.B, x.max_len, _ptr(out.data), int(out_f64),
+                        _ptr(bd), _ptr(ad), _ptr(zd), ncoef, int(filtfilt), _ptr(scr), _stream()), "aware_iir")
+    return out
+
+
+def segment_cut(x: Ragged, starts: Sequence[int], cuts: Sequence[int], zero_fill: bool) -> Ragged:
+    lib = load_library()
+    dev = x.data.device
+    out_len = x.lengths if zero_fill else [n - k for n, k in zip(x.lengths, cuts)]
+    out = Ragged(torch.empty(sum(out_len), dtype=torch.float32, device=dev), out_len)
+    st = torch.tensor(list(starts), dtype=torch.int32, device=dev)
+    ct = torch.tensor(list(cuts), dtype=torch.int32, device=dev)
+    check(lib.aware_segment_cut(_ptr(x.data), _ptr(x.d_off), _ptr(out.data), _ptr(out.d_off), _ptr(out.d_len), _ptr(st),
+                                _ptr(ct), int(zero_fill), x.B, out.max_len, _stream()), "aware_segment_cut")
+    return out
+
+
+def gaussian_noise(x: Ragged, snr_db: float, seeds: Sequence[int]) -> Ragged:
+    lib = load_library()
+    dev = x.data.device
+    out = x.like()
+    sd = torch.tensor([int(s) & 0x7FFFFFFF for s in seeds], dtype=torch.int32, device=dev)
+    scr = torch.empty(x.B * 8 + 64, dtype=torch.uint8, device=dev)
+    check(lib.aware_gaussian_noise(_ptr(x.data), _ptr(out.data), _ptr(x.d_off), _ptr(x.d_len), x.B, x.max_len, _ptr(sd),
+                                   float(snr_db), _ptr(scr), _stream()), "aware_gaussian_noise")
+    return out
+
+
+KERNEL_KINDS = ["synth", "analysis", "gemm", "mel_norm", "in_lrelu", "head", "synth_adjoint", "analysis_adjoint_nadam", "misc"]
+
+
+def embed_profile(sess: EmbedSession, n_iters: int = 3):
+    """Per-launch milliseconds of `n_iters` eager loop bodies, measured with HIP events recorded
+    on the launch stream (aware_embed_profile).  Returns a list of (kind_name, ms)."""
+    cap = 64 * n_iters
+    ms = (C.c_float * cap)()
+    kind = (C.c_int * cap)()
+    n = sess.lib.aware_embed_profile(sess.h, n_iters, cap, ms, kind, _stream())
+    if n < 0:
+        check(n, "aware_embed_profile")
+    return [(KERNEL_KINDS[kind[i]], float(ms[i])) for i in range(n)]

@@ -133,6 +133,12 @@ int aware_embed_begin(aware_embed* e, const float* audio, const float* target, v
 int aware_embed_iterate(aware_embed* e, int n_iters, void* stream);
 /* forward + backward without the optimiser step; grad: dev f32 [total frames][256] = dL/dcoef */
 int aware_embed_gradient(aware_embed* e, float* grad, void* stream);
+/* Timing aid for the roofline report: runs n_iters loop bodies eagerly with a HIP event recorded on
+ * `stream` after every kernel launch; writes the elapsed milliseconds between consecutive events and
+ * a kernel kind per launch (0 synth, 1 analysis, 2 gemm, 3 mel-norm, 4 in+lrelu, 5 head, 6 synth
+ * adjoint, 7 analysis adjoint + NAdam, 8 misc).  Synchronises the stream.  Returns the number of
+ * entries written or a negative error.  (These iterations DO step the optimiser.) */
+int aware_embed_profile(aware_embed* e, int n_iters, int max_entries, float* ms_out, int* kind_out, void* stream);
 /* final synthesis from the best coefficients (:173-194) and the service-level rescale
  * (service/embed.py:69,73): out[b] = rescale[b] * normalise(istft(...)).  rescale: dev f32 [B] or NULL. */
 int aware_embed_finish(aware_embed* e, const float* rescale, float* out, void* stream);
@@ -142,9 +148,13 @@ void* aware_embed_buffer(aware_embed* e, int which);
 
 /* ---- attacks (scripts/attacks.py) ------------------------------------------------------------------
  * All operate on ragged batches given by dev int32 arrays off[B], len[B]. */
-/* PCMBitDepthConversion.apply :44-70. bits in {8,12,16,24}.  scratch >= B*ceil(max_len/4096)*8 bytes */
+/* PCMBitDepthConversion.apply :44-70. bits in {8,12,16,24}.  scratch >= B*(ceil(max_len/4096)*8 + 4) bytes */
 int aware_pcm_quantize(const float* in, float* out, const int* off, const int* len, int B, int max_len,
                        int bits, void* scratch, void* stream);
+/* WaveformNormalizer.__call__ (src/AWARE/utils/audio/waveform.py:18-19) as a stand-alone op:
+ * out = in / max(|in| + 1e-8) per clip.  scratch as for aware_pcm_quantize (+ 4*B bytes). */
+int aware_waveform_normalize(const float* in, float* out, const int* off, const int* len, int B, int max_len,
+                             void* scratch, void* stream);
 /* scipy.signal.resample_poly's polyphase core (Resample.apply :290-293, scripts/test.py:60-63):
  * out[j] = sum_i in[i] * h[j*down - i*up + half_len], fp32.  h: dev f32 [nh] (already scaled by up). */
 int aware_upfirdn(const float* in, const int* in_off, const int* in_len, float* out, const int* out_off,

@@ -1,0 +1,27 @@
+"""Ad-hoc timing of the embed iteration (development aid, not the contract bench)."""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from aware_amd import runtime as rt
+from oracle import aware_oracle as O
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+graph = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+n = 48000
+plan = rt.Plan()
+ws, bs = O.detector_weights()
+det = rt.DetectorWeights(plan, O.mel_filter_bank(), [w.numpy() for w in ws], [b.numpy() for b in bs])
+batch = rt.Batch([n] * B)
+g = torch.Generator(device="cuda").manual_seed(0)
+audio = 0.1 * torch.randn(B * n, device="cuda", generator=g)
+target = (torch.randint(0, 2, (B, 20), device="cuda", generator=g).float() * 2 - 1)
+sess = rt.EmbedSession(plan, det, batch, use_graph=bool(graph))
+sess.begin(audio, target)
+sess.iterate(5)
+torch.cuda.synchronize()
+t0 = time.time()
+sess.iterate(iters)
+torch.cuda.synchronize()
+dt = (time.time() - t0) / iters
+print(f"B={B} graph={graph}: {dt*1e3:.3f} ms/iter -> embed 400 iters = {dt*400:.3f} s -> {B*3/(dt*400):.1f} wf-s/s; loss[0]={float(sess.loss[0]):.4f}")
