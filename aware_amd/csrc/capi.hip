@@ -345,7 +345,8 @@ struct DetBufs {
     float* x0;        // [NP][128]
     float* act[8];    // [NP][C_l+1]
     float* rstd[8];   // [B][C_l+1]
-    float *mu, *rs, *gstat;
+    float *mstats, *gstat, *mpart;   // mel statistics [B][128][4], [B][4], chunk partials
+    int mstride;
     float* pred;      // [B][nbits]
 };
 static void carve_det(Carver& c, const aware_batch* b, const aware_detector* d, DetBufs& o) {
@@ -355,13 +356,15 @@ static void carve_det(Carver& c, const aware_batch* b, const aware_detector* d, 
         o.act[l] = c.take<float>((size_t)b->NP * d->ch[l + 1]);
         o.rstd[l] = c.take<float>((size_t)b->B * d->ch[l + 1]);
     }
-    o.mu = c.take<float>((size_t)b->B * 128);
-    o.rs = c.take<float>((size_t)b->B * 128);
+    o.mstats = c.take<float>((size_t)b->B * 128 * 4);
     o.gstat = c.take<float>((size_t)b->B * 4);
+    o.mstride = (b->max_frames + 31) / 32;
+    o.mpart = c.take<float>((size_t)b->B * o.mstride * 256);
     o.pred = c.take<float>((size_t)b->B * d->nbits);
 }
 static size_t det_bytes(const aware_batch* b, const aware_detector* d) {
-    size_t f = (size_t)b->NF * 128 + (size_t)b->NP * 128 + (size_t)b->B * (128 * 2 + 4 + d->nbits);
+    size_t f = (size_t)b->NF * 128 + (size_t)b->NP * 128 + (size_t)b->B * (128 * 4 + 4 + d->nbits) +
+               (size_t)b->B * ((b->max_frames + 31) / 32) * 256;
     for (int l = 0; l < d->n_layers; ++l) f += (size_t)(b->NP + b->B) * d->ch[l + 1];
     return f * sizeof(float) + 256 * (8 + 2 * d->n_layers);
 }
@@ -370,14 +373,15 @@ static size_t det_bytes(const aware_batch* b, const aware_detector* d) {
 static int det_forward(const aware_detector* d, const aware_batch* b, const float* mag, DetBufs& o, hipStream_t st) {
     launch_gemm_nt(mag, kFS, d->melT, kFS, nullptr, o.xm, 128, b->NF, 128, kFS, st);
     LAUNCHCHK(); PROF(K_GEMM);
-    launch_mel_norm_fwd(o.xm, b->d_frame_off, b->d_pool_off, o.x0, o.mu, o.rs, o.gstat, b->B, st);
+    launch_mel_norm_fwd(o.xm, b->d_frame_off, b->d_pool_off, o.x0, o.mstats, o.gstat, o.mpart, o.mstride, b->B,
+                        b->max_frames, st);
     LAUNCHCHK(); PROF(K_MELNORM);
     const float* x = o.x0;
     for (int l = 0; l < d->n_layers; ++l) {
         const int ci = d->ch[l], co = d->ch[l + 1];
         launch_gemm_nt(x, ci, d->w[l], ci, d->bias[l], o.act[l], co, b->NP, co, ci, st);
         LAUNCHCHK(); PROF(K_GEMM);
-        launch_in_lrelu_fwd(o.act[l], b->d_pool_off, o.rstd[l], co, b->B, st);
+        launch_in_lrelu_fwd(o.act[l], b->d_pool_off, o.rstd[l], co, b->B, b->max_frames / 2, st);
         LAUNCHCHK(); PROF(K_INLRELU);
         x = o.act[l];
     }
@@ -446,8 +450,8 @@ struct aware_embed {
     unsigned long long *pmaxA, *pmaxY;
     double* pdot;
     float hyp[4];
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t gexec = nullptr;
+    hipGraph_t graph = nullptr, graphN = nullptr;
+    hipGraphExec_t gexec = nullptr, gexecN = nullptr;
     hipStream_t cap = nullptr;        // private stream used only to record the graph
 };
 
@@ -517,6 +521,8 @@ extern "C" void aware_embed_destroy(aware_embed* e) {
     if (!e) return;
     if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
     if (e->graph) (void)hipGraphDestroy(e->graph);
+    if (e->gexecN) (void)hipGraphExecDestroy(e->gexecN);
+    if (e->graphN) (void)hipGraphDestroy(e->graphN);
     if (e->cap) (void)hipStreamDestroy(e->cap);
     delete e;
 }
@@ -603,13 +609,14 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
     // :111 backward through the detector (data gradients only; weights are frozen :76-77)
     for (int l = nl - 1; l >= 0; --l) {
         const int ci = d->ch[l], co = d->ch[l + 1];
-        launch_in_lrelu_bwd(dA, e->db.act[l], b->d_pool_off, e->db.rstd[l], co, b->B, st);
+        launch_in_lrelu_bwd(dA, e->db.act[l], b->d_pool_off, e->db.rstd[l], co, b->B, b->max_frames / 2, st);
         LAUNCHCHK(); PROF(K_INLRELU);
         launch_gemm_nt(dA, co, d->wT[l], co, nullptr, dB, ci, b->NP, ci, co, st);
         LAUNCHCHK(); PROF(K_GEMM);
         float* t = dA; dA = dB; dB = t;
     }
-    launch_mel_norm_bwd(dA, e->db.xm, b->d_frame_off, b->d_pool_off, e->db.mu, e->db.rs, e->db.gstat, b->B, st);
+    launch_mel_norm_bwd(dA, e->db.xm, b->d_frame_off, b->d_pool_off, e->db.mstats, e->db.gstat, e->db.mpart,
+                        e->db.mstride, b->B, b->max_frames, st);
     LAUNCHCHK(); PROF(K_MELNORM);
     launch_gemm_nt(e->db.xm, 128, d->melB, 128, nullptr, e->gmag, kFS, b->NF, kFS, 128, st);
     LAUNCHCHK(); PROF(K_GEMM);
@@ -648,18 +655,29 @@ extern "C" int aware_embed_iterate(aware_embed* e, int n_iters, void* stream) {
         }
         return AWARE_OK;
     }
+    // Two graphs: one loop body, and kGraphIters loop bodies (amortises the replay floor).  The
+    // caller's stream may be the legacy default stream, which cannot be captured: record on a
+    // private stream, replay on the caller's.  All kernel arguments are iteration-invariant
+    // (the optimiser step index lives in device memory), so one recording serves every replay.
+    constexpr int kGraphIters = 16;
     if (!e->gexec) {
-        // the caller's stream may be the legacy default stream, which cannot be captured:
-        // record the iteration on a private stream, replay it on the caller's
         if (!e->cap) HIPCHK(hipStreamCreateWithFlags(&e->cap, hipStreamNonBlocking));
-        HIPCHK(hipStreamBeginCapture(e->cap, hipStreamCaptureModeThreadLocal));
-        int rc = embed_iteration(e, e->cap, 1, nullptr);
-        hipError_t ce = hipStreamEndCapture(e->cap, &e->graph);
-        if (rc) return rc;
-        HIPCHK(ce);
-        HIPCHK(hipGraphInstantiate(&e->gexec, e->graph, nullptr, nullptr, 0));
+        for (int which = 0; which < 2; ++which) {
+            HIPCHK(hipStreamBeginCapture(e->cap, hipStreamCaptureModeThreadLocal));
+            int rc = AWARE_OK;
+            for (int i = 0; i < (which ? kGraphIters : 1) && rc == AWARE_OK; ++i) rc = embed_iteration(e, e->cap, 1, nullptr);
+            hipGraph_t g = nullptr;
+            hipError_t ce = hipStreamEndCapture(e->cap, &g);
+            if (rc) return rc;
+            HIPCHK(ce);
+            hipGraphExec_t ge = nullptr;
+            HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            if (which) { e->graphN = g; e->gexecN = ge; } else { e->graph = g; e->gexec = ge; }
+        }
     }
-    for (int i = 0; i < n_iters; ++i) HIPCHK(hipGraphLaunch(e->gexec, st));
+    int left = n_iters;
+    for (; left >= kGraphIters; left -= kGraphIters) HIPCHK(hipGraphLaunch(e->gexecN, st));
+    for (; left > 0; --left) HIPCHK(hipGraphLaunch(e->gexec, st));
     return AWARE_OK;
 }
 

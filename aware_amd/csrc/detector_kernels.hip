@@ -157,94 +157,169 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 
 // ---------------------------------------------------------------------------------
 // mel block: InstanceNorm1d(128) over time -> GlobalStandardize (per clip, unbiased
-// std) -> AvgPool1d(2,2).  One workgroup per clip: 128 channels x 2 row groups.
-// gstat[b] = {global mean a, 1/(s+1e-8), s, n}
+// std) -> AvgPool1d(2,2), and its backward.  Time is cut into 32-frame chunks so that
+// B * ceil(T/32) workgroups share the work; per-channel statistics are produced as
+// per-chunk (count, mean, M2) partials and merged with Chan's formula by every consumer
+// workgroup in fixed order (deterministic, no atomics).
+//
+// With u = (x - mu_c) * rs_c the per-channel sums are  sum_t u = 0  and
+// sum_t u^2 = rs_c^2 * M2_c  exactly, so the clip-wide mean of u is taken as 0 (the
+// reference evaluates a rounding residue of order 1e-9 there, globalStandardize.py:17)
+// and its unbiased std follows from the per-channel M2.
+// stats[b][c] = {mu, rs, M2, -};  gstat[b] = {1/(s+1e-8), s, n, T}
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void mel_norm_fwd_kernel(const float* __restrict__ xm, const int* __restrict__ frame_off,
-                                                            const int* __restrict__ pool_off, float* __restrict__ x0,
-                                                            float* __restrict__ mu_out, float* __restrict__ rs_out,
-                                                            float* __restrict__ gstat) {
-    __shared__ float s1[2][128], s2[2][128], smu[128], srs[128], red[4];
-    const int b = blockIdx.x;
+constexpr int kMelChunk = 32;
+
+__global__ __launch_bounds__(256) void mel_partial_stats_kernel(const float* __restrict__ xm, const int* __restrict__ frame_off,
+                                                                 float* __restrict__ part, int pstride) {
+    __shared__ float s1[2][128];
+    const int b = blockIdx.y;
     const int f0 = frame_off[b], T = frame_off[b + 1] - f0;
+    const int t0 = blockIdx.x * kMelChunk;
+    if (t0 >= T) return;
+    const int nt = min(kMelChunk, T - t0);
     const int c = threadIdx.x & 127, g = threadIdx.x >> 7;
-    const float* x = xm + (size_t)f0 * 128;
+    const float* x = xm + (size_t)(f0 + t0) * 128 + c;
+    float v[kMelChunk / 2];
     float a = 0.f;
-    for (int t = g; t < T; t += 2) a += x[(size_t)t * 128 + c];
+#pragma unroll
+    for (int i = 0; i < kMelChunk / 2; ++i) {
+        const int t = 2 * i + g;
+        v[i] = (t < nt) ? x[(size_t)t * 128] : 0.f;
+        a += v[i];
+    }
     s1[g][c] = a;
     __syncthreads();
-    const float mu = (s1[0][c] + s1[1][c]) / (float)T;
-    float q = 0.f, d1 = 0.f;
-    for (int t = g; t < T; t += 2) { float d = x[(size_t)t * 128 + c] - mu; q += d * d; d1 += d; }
-    s2[g][c] = q;
+    const float mean = (s1[0][c] + s1[1][c]) / (float)nt;
     __syncthreads();
-    s1[g][c] = d1;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMelChunk / 2; ++i) {
+        const int t = 2 * i + g;
+        if (t < nt) { float d = v[i] - mean; q += d * d; }
+    }
+    s1[g][c] = q;
     __syncthreads();
-    const float var = (s2[0][c] + s2[1][c]) / (float)T;           // biased, eps 1e-5
-    const float rs = 1.0f / sqrtf(var + 1e-5f);
-    if (g == 0) { smu[c] = mu; srs[c] = rs; mu_out[b * 128 + c] = mu; rs_out[b * 128 + c] = rs; }
-    // global statistics of u = (x - mu) * rs over all T*128 elements
-    float su = 0.f, suu = 0.f;
-    if (g == 0) { su = rs * (s1[0][c] + s1[1][c]); suu = rs * rs * (s2[0][c] + s2[1][c]); }
-    su = block_sum(su, red);
-    suu = block_sum(suu, red);
-    const float n = (float)T * 128.f;
-    const float ga = su / n;
-    float ss = suu - n * ga * ga;
-    if (ss < 0.f) ss = 0.f;
-    const float gs = sqrtf(ss / (n - 1.f));                       // unbiased std
-    const float ginv = 1.0f / (gs + 1e-8f);
-    if (threadIdx.x == 0) { gstat[b * 4 + 0] = ga; gstat[b * 4 + 1] = ginv; gstat[b * 4 + 2] = gs; gstat[b * 4 + 3] = n; }
-    const int Tp = T / 2;
-    float* o = x0 + (size_t)pool_off[b] * 128;
-    for (int t = g; t < Tp; t += 2) {
-        float u0 = (x[(size_t)(2 * t) * 128 + c] - mu) * rs;
-        float u1 = (x[(size_t)(2 * t + 1) * 128 + c] - mu) * rs;
-        o[(size_t)t * 128 + c] = 0.5f * ((u0 - ga) * ginv + (u1 - ga) * ginv);
+    if (g == 0) {
+        float* o = part + ((size_t)b * pstride + blockIdx.x) * 256;
+        o[c] = mean;
+        o[128 + c] = s1[0][c] + s1[1][c];
     }
 }
 
-// backward of the mel block, in place on xm (xm <- dL/dxm)
-__global__ __launch_bounds__(256) void mel_norm_bwd_kernel(const float* __restrict__ dx0, float* __restrict__ xm,
-                                                            const int* __restrict__ frame_off, const int* __restrict__ pool_off,
-                                                            const float* __restrict__ mu_in, const float* __restrict__ rs_in,
-                                                            const float* __restrict__ gstat) {
-    __shared__ float s1[2][128], s2[2][128], red[4];
-    const int b = blockIdx.x;
-    const int f0 = frame_off[b], T = frame_off[b + 1] - f0, Tp = T / 2;
-    const int c = threadIdx.x & 127, g = threadIdx.x >> 7;
-    float* x = xm + (size_t)f0 * 128;
-    const float* d0 = dx0 + (size_t)pool_off[b] * 128;
-    const float mu = mu_in[b * 128 + c], rs = rs_in[b * 128 + c];
-    const float ga = gstat[b * 4 + 0], ginv = gstat[b * 4 + 1], gs = gstat[b * 4 + 2], n = gstat[b * 4 + 3];
-    // pass A: sum dv and sum dv*(u-a) over the whole clip (dv = dx0/2 on pooled frames)
-    float sa = 0.f, sb = 0.f;
-    for (int t = g; t < 2 * Tp; t += 2) {
-        float dv = 0.5f * d0[(size_t)(t >> 1) * 128 + c];
-        float u = (x[(size_t)t * 128 + c] - mu) * rs;
-        sa += dv; sb += dv * (u - ga);
+// merge the chunk partials of channel c (all threads with the same c get the same result)
+__device__ __forceinline__ void mel_merge(const float* __restrict__ part, int nchunk, int T, int c, float& mean, float& M2) {
+    float n = 0.f;
+    mean = 0.f; M2 = 0.f;
+    for (int k = 0; k < nchunk; ++k) {
+        const float nk = (float)min(kMelChunk, T - k * kMelChunk);
+        const float mk = part[(size_t)k * 256 + c], qk = part[(size_t)k * 256 + 128 + c];
+        const float d = mk - mean, nn = n + nk;
+        mean += d * (nk / nn);
+        M2 += qk + d * d * (n * nk / nn);
+        n = nn;
     }
-    sa = block_sum(sa, red);
-    sb = block_sum(sb, red);
+}
+
+__global__ __launch_bounds__(256) void mel_apply_pool_kernel(const float* __restrict__ xm, const int* __restrict__ frame_off,
+                                                              const int* __restrict__ pool_off, const float* __restrict__ part,
+                                                              int pstride, float* __restrict__ x0, float* __restrict__ stats,
+                                                              float* __restrict__ gstat) {
+    __shared__ float red[4];
+    const int b = blockIdx.y;
+    const int f0 = frame_off[b], T = frame_off[b + 1] - f0;
+    const int t0 = blockIdx.x * kMelChunk;
+    if (t0 >= T) return;
+    const int nchunk = (T + kMelChunk - 1) / kMelChunk;
+    const int c = threadIdx.x & 127, g = threadIdx.x >> 7;
+    float mu, M2;
+    mel_merge(part + (size_t)b * pstride * 256, nchunk, T, c, mu, M2);
+    const float rs = 1.0f / sqrtf(M2 / (float)T + 1e-5f);            // biased var, eps 1e-5
+    float suu = (g == 0) ? rs * rs * M2 : 0.f;
+    suu = block_sum(suu, red);
+    const float n = (float)T * 128.f;
+    const float gs = sqrtf(suu / (n - 1.f));                          // unbiased std of u (mean 0)
+    const float ginv = 1.0f / (gs + 1e-8f);
+    if (blockIdx.x == 0) {
+        if (g == 0) { float* st = stats + ((size_t)b * 128 + c) * 4; st[0] = mu; st[1] = rs; st[2] = M2; st[3] = 0.f; }
+        if (threadIdx.x == 0) { gstat[b * 4 + 0] = ginv; gstat[b * 4 + 1] = gs; gstat[b * 4 + 2] = n; gstat[b * 4 + 3] = (float)T; }
+    }
+    // pooled frames tp = t0/2 .. ; chunk is even-sized so pairs never straddle chunks
+    const int Tp = T / 2;
+    const float* x = xm + (size_t)f0 * 128 + c;
+    float* o = x0 + (size_t)pool_off[b] * 128 + c;
+    const int tp0 = t0 / 2, tp1 = min(Tp, tp0 + kMelChunk / 2);
+    for (int tp = tp0 + g; tp < tp1; tp += 2) {
+        float u0 = (x[(size_t)(2 * tp) * 128] - mu) * rs;
+        float u1 = (x[(size_t)(2 * tp + 1) * 128] - mu) * rs;
+        o[(size_t)tp * 128] = 0.5f * (u0 * ginv + u1 * ginv);
+    }
+}
+
+// backward partials: D1_c = sum_t dv, D2_c = sum_t dv*u over the chunk (dv = dx0/2 on pooled frames)
+__global__ __launch_bounds__(256) void mel_bwd_partial_kernel(const float* __restrict__ dx0, const float* __restrict__ xm,
+                                                               const int* __restrict__ frame_off, const int* __restrict__ pool_off,
+                                                               const float* __restrict__ stats, float* __restrict__ part,
+                                                               int pstride) {
+    __shared__ float s1[2][128], s2[2][128];
+    const int b = blockIdx.y;
+    const int f0 = frame_off[b], T = frame_off[b + 1] - f0, Tp = T / 2;
+    const int t0 = blockIdx.x * kMelChunk;
+    if (t0 >= T) return;
+    const int c = threadIdx.x & 127, g = threadIdx.x >> 7;
+    const float* st = stats + ((size_t)b * 128 + c) * 4;
+    const float mu = st[0], rs = st[1];
+    const float* x = xm + (size_t)f0 * 128 + c;
+    const float* d0 = dx0 + (size_t)pool_off[b] * 128 + c;
+    const int tp0 = t0 / 2, tp1 = min(Tp, tp0 + kMelChunk / 2);
+    float a1 = 0.f, a2 = 0.f;
+    for (int tp = tp0 + g; tp < tp1; tp += 2) {
+        const float dv = 0.5f * d0[(size_t)tp * 128];
+        const float u0 = (x[(size_t)(2 * tp) * 128] - mu) * rs, u1 = (x[(size_t)(2 * tp + 1) * 128] - mu) * rs;
+        a1 += 2.f * dv;
+        a2 += dv * u0 + dv * u1;
+    }
+    s1[g][c] = a1; s2[g][c] = a2;
+    __syncthreads();
+    if (g == 0) {
+        float* o = part + ((size_t)b * pstride + blockIdx.x) * 256;
+        o[c] = s1[0][c] + s1[1][c];
+        o[128 + c] = s2[0][c] + s2[1][c];
+    }
+}
+
+// backward apply, in place on xm (xm <- dL/dxm)
+__global__ __launch_bounds__(256) void mel_bwd_apply_kernel(const float* __restrict__ dx0, float* __restrict__ xm,
+                                                             const int* __restrict__ frame_off, const int* __restrict__ pool_off,
+                                                             const float* __restrict__ stats, const float* __restrict__ gstat,
+                                                             const float* __restrict__ part, int pstride) {
+    __shared__ float red[4];
+    const int b = blockIdx.y;
+    const int f0 = frame_off[b], T = frame_off[b + 1] - f0, Tp = T / 2;
+    const int t0 = blockIdx.x * kMelChunk;
+    if (t0 >= T) return;
+    const int nchunk = (T + kMelChunk - 1) / kMelChunk;
+    const int c = threadIdx.x & 127, g = threadIdx.x >> 7;
+    const float* st = stats + ((size_t)b * 128 + c) * 4;
+    const float mu = st[0], rs = st[1], M2 = st[2];
+    const float ginv = gstat[b * 4 + 0], gs = gstat[b * 4 + 1], n = gstat[b * 4 + 2];
+    float D1 = 0.f, D2 = 0.f;
+    const float* pp = part + (size_t)b * pstride * 256;
+    for (int k = 0; k < nchunk; ++k) { D1 += pp[(size_t)k * 256 + c]; D2 += pp[(size_t)k * 256 + 128 + c]; }
+    const float sa = block_sum(g == 0 ? D1 : 0.f, red);
+    const float sb = block_sum(g == 0 ? D2 : 0.f, red);
     const float mdv = sa / n;
     const float Q = (gs > 0.f) ? sb * ginv * ginv / ((n - 1.f) * gs) : 0.f;
-    // pass B: per-channel sums of du and du*u
-    float p1 = 0.f, p2 = 0.f;
-    for (int t = g; t < T; t += 2) {
-        float dv = (t < 2 * Tp) ? 0.5f * d0[(size_t)(t >> 1) * 128 + c] : 0.f;
-        float u = (x[(size_t)t * 128 + c] - mu) * rs;
-        float du = (dv - mdv) * ginv - (u - ga) * Q;
-        p1 += du; p2 += du * u;
-    }
-    s1[g][c] = p1; s2[g][c] = p2;
-    __syncthreads();
-    const float m1 = (s1[0][c] + s1[1][c]) / (float)T, m2 = (s2[0][c] + s2[1][c]) / (float)T;
-    // pass C: InstanceNorm backward, overwrite x
-    for (int t = g; t < T; t += 2) {
-        float dv = (t < 2 * Tp) ? 0.5f * d0[(size_t)(t >> 1) * 128 + c] : 0.f;
-        float u = (x[(size_t)t * 128 + c] - mu) * rs;
-        float du = (dv - mdv) * ginv - (u - ga) * Q;
-        x[(size_t)t * 128 + c] = rs * (du - m1 - u * m2);
+    const float m1 = ginv * (D1 / (float)T - mdv);
+    const float m2 = (ginv * D2 - Q * rs * rs * M2) / (float)T;
+    float* x = xm + (size_t)f0 * 128 + c;
+    const float* d0 = dx0 + (size_t)pool_off[b] * 128 + c;
+    const int t1 = min(T, t0 + kMelChunk);
+    for (int t = t0 + g; t < t1; t += 2) {
+        const float dv = (t < 2 * Tp) ? 0.5f * d0[(size_t)(t >> 1) * 128] : 0.f;
+        const float u = (x[(size_t)t * 128] - mu) * rs;
+        const float du = (dv - mdv) * ginv - u * Q;
+        x[(size_t)t * 128] = rs * (du - m1 - u * m2);
     }
 }
 
@@ -276,6 +351,87 @@ __global__ __launch_bounds__(256) void in_lrelu_fwd_kernel(float* __restrict__ z
     if (ok) for (int t = g; t < Tp; t += 4) {
         float u = (x[(size_t)t * C] - mu) * rs;
         x[(size_t)t * C] = u > 0.f ? u : 0.2f * u;
+    }
+}
+
+// Register-resident variants for clips of up to 4*R pooled frames (R rows per thread): the
+// activation is read once and written once.
+template <int R>
+__global__ __launch_bounds__(256) void in_lrelu_fwd_reg_kernel(float* __restrict__ z, const int* __restrict__ pool_off,
+                                                                float* __restrict__ rstd, int C) {
+    __shared__ float s[4][64];
+    const int b = blockIdx.y, c0 = blockIdx.x * 64;
+    const int r0 = pool_off[b], Tp = pool_off[b + 1] - r0;
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6, c = c0 + cl;
+    if (Tp <= 0) return;
+    const bool ok = c < C;
+    float* x = z + (size_t)r0 * C + c;
+    float v[R];
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int t = g + 4 * i;
+        v[i] = (ok && t < Tp) ? x[(size_t)t * C] : 0.f;
+        a += v[i];
+    }
+    s[g][cl] = a;
+    __syncthreads();
+    const float mu = (s[0][cl] + s[1][cl] + s[2][cl] + s[3][cl]) / (float)Tp;
+    __syncthreads();
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int t = g + 4 * i;
+        if (t < Tp) { float d = v[i] - mu; q += d * d; }
+    }
+    s[g][cl] = q;
+    __syncthreads();
+    const float rs = 1.0f / sqrtf((s[0][cl] + s[1][cl] + s[2][cl] + s[3][cl]) / (float)Tp + 1e-5f);
+    if (ok && g == 0) rstd[(size_t)b * C + c] = rs;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int t = g + 4 * i;
+        if (ok && t < Tp) {
+            float u = (v[i] - mu) * rs;
+            x[(size_t)t * C] = u > 0.f ? u : 0.2f * u;
+        }
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void in_lrelu_bwd_reg_kernel(float* __restrict__ dA, const float* __restrict__ A,
+                                                                const int* __restrict__ pool_off, const float* __restrict__ rstd,
+                                                                int C) {
+    __shared__ float s1[4][64], s2[4][64];
+    const int b = blockIdx.y, c0 = blockIdx.x * 64;
+    const int r0 = pool_off[b], Tp = pool_off[b + 1] - r0;
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6, c = c0 + cl;
+    if (Tp <= 0) return;
+    const bool ok = c < C;
+    float* d = dA + (size_t)r0 * C + c;
+    const float* a = A + (size_t)r0 * C + c;
+    float du[R], u[R];
+    float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int t = g + 4 * i;
+        du[i] = 0.f; u[i] = 0.f;
+        if (ok && t < Tp) {
+            const float av = a[(size_t)t * C];
+            u[i] = av > 0.f ? av : av * 5.0f;            // invert LeakyReLU(0.2)
+            du[i] = d[(size_t)t * C] * (av > 0.f ? 1.f : 0.2f);
+        }
+        p1 += du[i]; p2 += du[i] * u[i];
+    }
+    s1[g][cl] = p1; s2[g][cl] = p2;
+    __syncthreads();
+    const float m1 = (s1[0][cl] + s1[1][cl] + s1[2][cl] + s1[3][cl]) / (float)Tp;
+    const float m2 = (s2[0][cl] + s2[1][cl] + s2[2][cl] + s2[3][cl]) / (float)Tp;
+    const float rs = ok ? rstd[(size_t)b * C + c] : 0.f;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int t = g + 4 * i;
+        if (ok && t < Tp) d[(size_t)t * C] = rs * (du[i] - m1 - u[i] * m2);
     }
 }
 
@@ -315,24 +471,24 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_kernel(float* __restrict__ d
 // loss_kind: 0 push_extremes, 1 mse, 2 hinge, 3 sign  (embedding/losses.py)
 // If dA3 == nullptr only the prediction is produced (detect path).
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void head_kernel(const float* __restrict__ a3, const int* __restrict__ pool_off,
-                                                   const float* __restrict__ target, float* __restrict__ pred,
-                                                   float* __restrict__ loss_out, float* __restrict__ best_loss,
-                                                   int* __restrict__ improved, float* __restrict__ dA3, int loss_kind,
-                                                   int nbits) {
-    __shared__ float mean[64], dm[64];
-    const int b = blockIdx.x, c = threadIdx.x;
+__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ a3, const int* __restrict__ pool_off,
+                                                    const float* __restrict__ target, float* __restrict__ pred,
+                                                    float* __restrict__ loss_out, float* __restrict__ best_loss,
+                                                    int* __restrict__ improved, float* __restrict__ dA3, int loss_kind,
+                                                    int nbits) {
+    __shared__ float part[4][64], mean[64], dm[64];
+    const int b = blockIdx.x, c = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int r0 = pool_off[b], Tp = pool_off[b + 1] - r0;
     const int C = 2 * nbits;
     float m = 0.f;
-    if (c < C) {
-        for (int t = 0; t < Tp; ++t) m += a3[(size_t)(r0 + t) * C + c];
-        m /= (float)Tp;
-    }
-    mean[c] = m;
+    if (c < C)
+        for (int t = g; t < Tp; t += 4) m += a3[(size_t)(r0 + t) * C + c];
+    part[g][c] = m;
+    __syncthreads();
+    if (g == 0) mean[c] = (part[0][c] + part[1][c] + part[2][c] + part[3][c]) / (float)Tp;
     __syncthreads();
     float lterm = 0.f, dp = 0.f, p = 0.f;
-    if (c < nbits) {
+    if (g == 0 && c < nbits) {
         p = tanhf(mean[2 * c] - mean[2 * c + 1]);
         pred[b * nbits + c] = p;
         if (target) {
@@ -356,45 +512,61 @@ __global__ __launch_bounds__(64) void head_kernel(const float* __restrict__ a3, 
         }
     }
     if (!target) return;
-    float L = wave_sum(lterm);
-    if (c == 0) {
-        loss_out[b] = L;
-        const float bl = best_loss[b];
-        const int imp = L < bl;
-        improved[b] = imp;
-        if (imp) best_loss[b] = L;
+    if (g == 0) {
+        float L = wave_sum(lterm);
+        if (c == 0) {
+            loss_out[b] = L;
+            const float bl = best_loss[b];
+            const int imp = L < bl;
+            improved[b] = imp;
+            if (imp) best_loss[b] = L;
+        }
+        if (dA3 && c < nbits) {
+            const float dpre = dp * (1.f - p * p);             // tanh'
+            dm[2 * c] = dpre; dm[2 * c + 1] = -dpre;
+        }
     }
     if (!dA3) return;
-    const float dpre = dp * (1.f - p * p);                 // tanh'
-    if (c < nbits) { dm[2 * c] = dpre; dm[2 * c + 1] = -dpre; }
     __syncthreads();
     if (c < C) {
         const float gv = dm[c] / (float)Tp;
-        for (int t = 0; t < Tp; ++t) dA3[(size_t)(r0 + t) * C + c] = gv;
+        for (int t = g; t < Tp; t += 4) dA3[(size_t)(r0 + t) * C + c] = gv;
     }
 }
 
 __global__ void advance_step_kernel(int* step) { if (threadIdx.x == 0 && blockIdx.x == 0) *step += 1; }
 
-void launch_mel_norm_fwd(const float* xm, const int* frame_off, const int* pool_off, float* x0, float* mu, float* rs,
-                         float* gstat, int B, hipStream_t st) {
-    hipLaunchKernelGGL(mel_norm_fwd_kernel, dim3(B), dim3(256), 0, st, xm, frame_off, pool_off, x0, mu, rs, gstat);
+void launch_mel_norm_fwd(const float* xm, const int* frame_off, const int* pool_off, float* x0, float* stats,
+                         float* gstat, float* part, int pstride, int B, int max_frames, hipStream_t st) {
+    const int nx = (max_frames + kMelChunk - 1) / kMelChunk;
+    hipLaunchKernelGGL(mel_partial_stats_kernel, dim3(nx, B), dim3(256), 0, st, xm, frame_off, part, pstride);
+    hipLaunchKernelGGL(mel_apply_pool_kernel, dim3(nx, B), dim3(256), 0, st, xm, frame_off, pool_off, part, pstride, x0, stats,
+                       gstat);
 }
-void launch_mel_norm_bwd(const float* dx0, float* xm, const int* frame_off, const int* pool_off, const float* mu,
-                         const float* rs, const float* gstat, int B, hipStream_t st) {
-    hipLaunchKernelGGL(mel_norm_bwd_kernel, dim3(B), dim3(256), 0, st, dx0, xm, frame_off, pool_off, mu, rs, gstat);
+void launch_mel_norm_bwd(const float* dx0, float* xm, const int* frame_off, const int* pool_off, const float* stats,
+                         const float* gstat, float* part, int pstride, int B, int max_frames, hipStream_t st) {
+    const int nx = (max_frames + kMelChunk - 1) / kMelChunk;
+    hipLaunchKernelGGL(mel_bwd_partial_kernel, dim3(nx, B), dim3(256), 0, st, dx0, xm, frame_off, pool_off, stats, part, pstride);
+    hipLaunchKernelGGL(mel_bwd_apply_kernel, dim3(nx, B), dim3(256), 0, st, dx0, xm, frame_off, pool_off, stats, gstat, part,
+                       pstride);
 }
-void launch_in_lrelu_fwd(float* z, const int* pool_off, float* rstd, int C, int B, hipStream_t st) {
-    hipLaunchKernelGGL(in_lrelu_fwd_kernel, dim3((C + 63) / 64, B), dim3(256), 0, st, z, pool_off, rstd, C);
+void launch_in_lrelu_fwd(float* z, const int* pool_off, float* rstd, int C, int B, int max_pooled, hipStream_t st) {
+    if (max_pooled <= 128)
+        hipLaunchKernelGGL(in_lrelu_fwd_reg_kernel<32>, dim3((C + 63) / 64, B), dim3(256), 0, st, z, pool_off, rstd, C);
+    else
+        hipLaunchKernelGGL(in_lrelu_fwd_kernel, dim3((C + 63) / 64, B), dim3(256), 0, st, z, pool_off, rstd, C);
 }
 void launch_in_lrelu_bwd(float* dA, const float* A, const int* pool_off, const float* rstd, int C, int B,
-                         hipStream_t st) {
-    hipLaunchKernelGGL(in_lrelu_bwd_kernel, dim3((C + 63) / 64, B), dim3(256), 0, st, dA, A, pool_off, rstd, C);
+                         int max_pooled, hipStream_t st) {
+    if (max_pooled <= 128)
+        hipLaunchKernelGGL(in_lrelu_bwd_reg_kernel<32>, dim3((C + 63) / 64, B), dim3(256), 0, st, dA, A, pool_off, rstd, C);
+    else
+        hipLaunchKernelGGL(in_lrelu_bwd_kernel, dim3((C + 63) / 64, B), dim3(256), 0, st, dA, A, pool_off, rstd, C);
 }
 void launch_head(const float* a3, const int* pool_off, const float* target, float* pred, float* loss,
                  float* best_loss, int* improved, float* dA3, int* step, int loss_kind, int nbits, int B,
                  hipStream_t st) {
-    hipLaunchKernelGGL(head_kernel, dim3(B), dim3(64), 0, st, a3, pool_off, target, pred, loss, best_loss, improved, dA3,
+    hipLaunchKernelGGL(head_kernel, dim3(B), dim3(256), 0, st, a3, pool_off, target, pred, loss, best_loss, improved, dA3,
                        loss_kind, nbits);
     (void)step;
 }

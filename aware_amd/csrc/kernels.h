@@ -71,15 +71,15 @@ void launch_finish(const float* yraw, const int* frame_off, const unsigned long 
 void launch_gemm_nt(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc, int M,
                     int N, int K, hipStream_t st);
 // mel block: InstanceNorm over time, per-clip GlobalStandardize, AvgPool(2,2)
-void launch_mel_norm_fwd(const float* xm, const int* frame_off, const int* pool_off, float* x0, float* mu, float* rs,
-                         float* gstat, int B, hipStream_t st);
-void launch_mel_norm_bwd(const float* dx0, float* xm_inout, const int* frame_off, const int* pool_off, const float* mu,
-                         const float* rs, const float* gstat, int B, hipStream_t st);
+void launch_mel_norm_fwd(const float* xm, const int* frame_off, const int* pool_off, float* x0, float* stats,
+                         float* gstat, float* part, int pstride, int B, int max_frames, hipStream_t st);
+void launch_mel_norm_bwd(const float* dx0, float* xm_inout, const int* frame_off, const int* pool_off, const float* stats,
+                         const float* gstat, float* part, int pstride, int B, int max_frames, hipStream_t st);
 // conv block tail: InstanceNorm over time + LeakyReLU(0.2), in place; saves rstd
-void launch_in_lrelu_fwd(float* z, const int* pool_off, float* rstd, int C, int B, hipStream_t st);
+void launch_in_lrelu_fwd(float* z, const int* pool_off, float* rstd, int C, int B, int max_pooled, hipStream_t st);
 // backward of the same, in place on dA (A is the post-activation output of the forward)
 void launch_in_lrelu_bwd(float* dA, const float* A, const int* pool_off, const float* rstd, int C, int B,
-                         hipStream_t st);
+                         int max_pooled, hipStream_t st);
 // BRH + loss + dL/dA3; also best-loss tracking
 void launch_head(const float* a3, const int* pool_off, const float* target, float* pred, float* loss,
                  float* best_loss, int* improved, float* dA3, int* step, int loss_kind, int nbits, int B,
