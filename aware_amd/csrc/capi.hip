@@ -514,6 +514,20 @@ extern "C" int aware_embed_create(aware_embed** out, const aware_plan* plan, con
     HIPCHK(hipMemcpyAsync(e->sched, sc.data(), sc.size() * sizeof(float4), hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));
     e->hyp[0] = (float)(1.0 - b1); e->hyp[1] = (float)b2; e->hyp[2] = (float)(1.0 - b2); e->hyp[3] = cfg->eps;
+    // measured tile choice for the ten GEMM shapes of this batch (a few ms, once per geometry;
+    // every configuration gives bit-identical results)
+    {
+        HIPCHK(hipMemsetAsync(e->d1, 0, (size_t)b->NP * det->maxc * sizeof(float), st));
+        HIPCHK(hipMemsetAsync(e->mag, 0, nsp * sizeof(float), st));
+        gemm_autotune(e->mag, kFS, det->melT, kFS, e->db.xm, 128, b->NF, 128, kFS, st);
+        gemm_autotune(e->db.xm, 128, det->melB, 128, e->gmag, kFS, b->NF, kFS, 128, st);
+        for (int l = 0; l < det->n_layers; ++l) {
+            const int ci = det->ch[l], co = det->ch[l + 1];
+            gemm_autotune(e->d1, ci, det->w[l], ci, e->d2, co, b->NP, co, ci, st);
+            gemm_autotune(e->d1, co, det->wT[l], co, e->d2, ci, b->NP, ci, co, st);
+        }
+        HIPCHK(hipStreamSynchronize(st));
+    }
     *out = e;
     return AWARE_OK;
 }
@@ -807,6 +821,15 @@ extern "C" int aware_gaussian_noise(const float* in, float* out, const int* off,
                                     const uint32_t* seeds, float snr_db, void* scratch, void* stream) {
     if (!in || !out || !seeds || !scratch || B < 1) return AWARE_E_BADARG;
     launch_gaussian_noise_full(in, out, off, len, seeds, (double*)scratch, snr_db, B, max_len, (hipStream_t)stream);
+    LAUNCHCHK();
+    return AWARE_OK;
+}
+
+extern "C" int aware_gemm_nt_variant(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C,
+                                     int ldc, int M, int N, int K, int variant, void* stream) {
+    if (!A || !Bt || !C || M < 1 || N < 1 || K < 4 || (K & 3) || (lda & 3) || (ldb & 3) || variant < 0 || variant > 12)
+        return AWARE_E_BADARG;
+    launch_gemm_nt_variant(A, lda, Bt, ldb, bias, C, ldc, M, N, K, variant, (hipStream_t)stream);
     LAUNCHCHK();
     return AWARE_OK;
 }

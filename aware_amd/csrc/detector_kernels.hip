@@ -22,21 +22,26 @@ namespace aware {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---------------------------------------------------------------------------------
-// fp32 MFMA GEMM, C = A * Bt^T + bias.  256 threads = 2x2 waves, BK = 32.
-// LDS rows are padded to 36 floats: the 16-lane groups of ds_read_b128 then hit 64
+// fp32 MFMA GEMM, C = A * Bt^T + bias.
+// Template: block tile BM x BN, NWM x NWN waves (each owns (BM/NWM) x (BN/NWN), a grid of
+// 32x32 MFMA tiles), K tile BK, DB = number of LDS buffers (1: two barriers per K tile,
+// 2: one barrier, next tile written while the current one is consumed).
+// LDS rows are padded to BK+4 floats: the 16-lane groups of ds_read_b128 then hit 64
 // distinct banks.  Within each group of 8 k, lane half h = lane>>5 takes k = 4h..4h+3
 // as four MFMA steps (any k permutation is legal as long as A and B agree).
 // ---------------------------------------------------------------------------------
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, int lda,
-                                                      const float* __restrict__ Bt, int ldb,
-                                                      const float* __restrict__ bias, float* __restrict__ C, int ldc,
-                                                      int M, int N, int K, int tiles_n, int ntiles) {
-    constexpr int BK = 32, LD = 36;
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-    constexpr int LA = BM / 32, LB = BN / 32;          // float4 loads per thread per tile
-    __shared__ float As[BM * LD];
-    __shared__ float Bs[BN * LD];
+template <int BM, int BN, int NWM, int NWN, int BK, int DB>
+__global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(const float* __restrict__ A, int lda,
+                                                                  const float* __restrict__ Bt, int ldb,
+                                                                  const float* __restrict__ bias, float* __restrict__ C,
+                                                                  int ldc, int M, int N, int K, int tiles_n, int ntiles) {
+    constexpr int NT = 64 * NWM * NWN, LD = BK + 4, KQ = BK / 4;
+    constexpr int WM = BM / NWM, WN = BN / NWN, TM = WM / 32, TN = WN / 32;
+    constexpr int RPP = NT / KQ;                       // rows covered by one pass of float4 loads
+    constexpr int LA = (BM + RPP - 1) / RPP, LB = (BN + RPP - 1) / RPP;
+    static_assert(WM % 32 == 0 && WN % 32 == 0 && BK % 8 == 0, "tile shape");
+    __shared__ float As[DB][BM * LD];
+    __shared__ float Bs[DB][BN * LD];
 
     // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, so give each
     // XCD a contiguous run of tiles (tiles of one row panel share A through that XCD's L2)
@@ -46,9 +51,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
     const int bn = (id % tiles_n) * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / NWN, wn = wave % NWN;
     const int li = lane & 31, lh = lane >> 5;
-    const int lrow = tid >> 3, lkq = (tid & 7) * 4;
+    const int lrow = tid / KQ, lkq = (tid % KQ) * 4;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -62,37 +67,35 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
     auto gload = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
-            int r = bm + lrow + 32 * i, k = k0 + lkq;
-            ra[i] = (r < M && k < K) ? *reinterpret_cast<const float4*>(A + (size_t)r * lda + k) : make_float4(0, 0, 0, 0);
+            int rl = lrow + RPP * i, r = bm + rl, k = k0 + lkq;
+            ra[i] = (rl < BM && r < M && k < K) ? *reinterpret_cast<const float4*>(A + (size_t)r * lda + k) : make_float4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
-            int r = bn + lrow + 32 * i, k = k0 + lkq;
-            rb[i] = (r < N && k < K) ? *reinterpret_cast<const float4*>(Bt + (size_t)r * ldb + k) : make_float4(0, 0, 0, 0);
+            int rl = lrow + RPP * i, r = bn + rl, k = k0 + lkq;
+            rb[i] = (rl < BN && r < N && k < K) ? *reinterpret_cast<const float4*>(Bt + (size_t)r * ldb + k) : make_float4(0, 0, 0, 0);
         }
     };
-    auto sstore = [&]() {
+    auto sstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < LA; ++i) *reinterpret_cast<float4*>(&As[(lrow + 32 * i) * LD + lkq]) = ra[i];
+        for (int i = 0; i < LA; ++i)
+            if (lrow + RPP * i < BM) *reinterpret_cast<float4*>(&As[buf][(lrow + RPP * i) * LD + lkq]) = ra[i];
 #pragma unroll
-        for (int i = 0; i < LB; ++i) *reinterpret_cast<float4*>(&Bs[(lrow + 32 * i) * LD + lkq]) = rb[i];
+        for (int i = 0; i < LB; ++i)
+            if (lrow + RPP * i < BN) *reinterpret_cast<float4*>(&Bs[buf][(lrow + RPP * i) * LD + lkq]) = rb[i];
     };
-
-    gload(0);
-    sstore();
-    __syncthreads();
-    for (int k0 = 0; k0 < K; k0 += BK) {
-        const bool more = (k0 + BK) < K;
-        if (more) gload(k0 + BK);
+    auto compute = [&](int buf) {
+        const float* as = As[buf];
+        const float* bs = Bs[buf];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < BK / 8; ++g) {
             float4 af[TM], bf[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                af[i] = *reinterpret_cast<const float4*>(&As[(wm * WM + i * 32 + li) * LD + 8 * g + 4 * lh]);
+                af[i] = *reinterpret_cast<const float4*>(&as[(wm * WM + i * 32 + li) * LD + 8 * g + 4 * lh]);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                bf[j] = *reinterpret_cast<const float4*>(&Bs[(wn * WN + j * 32 + li) * LD + 8 * g + 4 * lh]);
+                bf[j] = *reinterpret_cast<const float4*>(&bs[(wn * WN + j * 32 + li) * LD + 8 * g + 4 * lh]);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -103,10 +106,34 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
                 }
         }
-        __syncthreads();
-        if (more) {
-            sstore();
+    };
+
+    const int nk = (K + BK - 1) / BK;
+    gload(0);
+    sstore(0);
+    if (nk > 1) gload(BK);
+    __syncthreads();
+    if (DB == 2) {
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            compute(cur);
+            if (kt + 1 < nk) {
+                // buffer cur^1 was last read in iteration kt-1, which every wave left through the
+                // barrier below; the registers hold tile kt+1
+                sstore(cur ^ 1);
+                if (kt + 2 < nk) gload((kt + 2) * BK);
+            }
             __syncthreads();
+        }
+    } else {
+        for (int kt = 0; kt < nk; ++kt) {
+            compute(0);
+            __syncthreads();
+            if (kt + 1 < nk) {
+                sstore(0);
+                if (kt + 2 < nk) gload((kt + 2) * BK);
+                __syncthreads();
+            }
         }
     }
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
@@ -124,24 +151,94 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
         }
 }
 
+template <int BM, int BN, int NWM, int NWN, int BK, int DB>
+static void gemm_launch(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc, int M,
+                        int N, int K, hipStream_t st) {
+    int tn = (N + BN - 1) / BN, tm = (M + BM - 1) / BM;
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, NWM, NWN, BK, DB>), dim3(tn * tm), dim3(64 * NWM * NWN), 0, st, A, lda, Bt,
+                       ldb, bias, C, ldc, M, N, K, tn, tn * tm);
+}
+
+// Tile configurations.  All of them accumulate k in the same order, so the result of a GEMM
+// is bit-identical whichever one runs: choosing by measurement does not change numerics.
+constexpr int kNumGemmVariants = 12;
+static void gemm_dispatch(int variant, const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C,
+                          int ldc, int M, int N, int K, hipStream_t st) {
+#define GL(...) gemm_launch<__VA_ARGS__>(A, lda, Bt, ldb, bias, C, ldc, M, N, K, st)
+    switch (variant) {
+        case 1: GL(128, 128, 2, 2, 32, 1); break;
+        case 2: GL(128, 64, 2, 2, 32, 1); break;
+        case 3: GL(64, 64, 2, 2, 32, 2); break;
+        case 4: GL(64, 64, 2, 2, 32, 1); break;
+        case 5: GL(64, 64, 2, 2, 16, 2); break;
+        case 6: GL(64, 64, 2, 2, 64, 1); break;
+        case 7: GL(64, 128, 2, 2, 32, 1); break;
+        case 8: GL(128, 128, 4, 2, 16, 2); break;
+        case 9: GL(96, 64, 3, 2, 32, 1); break;
+        case 10: GL(128, 64, 4, 2, 32, 1); break;
+        case 11: GL(64, 128, 2, 4, 32, 1); break;
+        case 12: GL(128, 128, 4, 4, 32, 1); break;
+        default: GL(64, 64, 2, 2, 32, 1); break;
+    }
+#undef GL
+}
+
+// measured choice per shape (filled by gemm_autotune, e.g. from aware_embed_create)
+struct GemmChoice { int M, N, K, variant; };
+static GemmChoice g_choice[64];
+static int g_nchoice = 0;
+
+static int gemm_heuristic(int M, int N, int K) {
+    if (N <= 64) return 6;
+    if (K <= 64) return 5;
+    long t = (long)((M + 127) / 128) * ((N + 63) / 64);
+    return (t >= 700) ? 10 : 4;
+}
+static int gemm_lookup(int M, int N, int K) {
+    for (int i = 0; i < g_nchoice; ++i)
+        if (g_choice[i].M == M && g_choice[i].N == N && g_choice[i].K == K) return g_choice[i].variant;
+    return 0;
+}
+
+// Time every configuration on this shape (operands are scratch memory, contents irrelevant)
+// and remember the fastest.  Synchronises the stream; call outside graph capture.
+int gemm_autotune(const float* A, int lda, const float* Bt, int ldb, float* C, int ldc, int M, int N, int K,
+                  hipStream_t st) {
+    if (gemm_lookup(M, N, K)) return gemm_lookup(M, N, K);
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return gemm_heuristic(M, N, K);
+    int best = gemm_heuristic(M, N, K);
+    float best_ms = 1e30f;
+    for (int v = 1; v <= kNumGemmVariants; ++v) {
+        if (N <= 64 && (v == 1 || v == 7 || v == 8 || v == 11 || v == 12)) continue;     // >= 128-wide tiles
+        gemm_dispatch(v, A, lda, Bt, ldb, nullptr, C, ldc, M, N, K, st);                    // warm-up
+        (void)hipEventRecord(e0, st);
+        for (int r = 0; r < 4; ++r) gemm_dispatch(v, A, lda, Bt, ldb, nullptr, C, ldc, M, N, K, st);
+        (void)hipEventRecord(e1, st);
+        if (hipEventSynchronize(e1) != hipSuccess) break;
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best_ms) { best_ms = ms; best = v; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (g_nchoice < 64) g_choice[g_nchoice++] = GemmChoice{M, N, K, best};
+    return best;
+}
+
+// variant: 0 = automatic (measured choice if the shape was tuned, else a heuristic)
+void launch_gemm_nt_variant(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc,
+                            int M, int N, int K, int variant, hipStream_t st) {
+    if (variant == 0) {
+        variant = gemm_lookup(M, N, K);
+        if (!variant) variant = gemm_heuristic(M, N, K);
+    }
+    gemm_dispatch(variant, A, lda, Bt, ldb, bias, C, ldc, M, N, K, st);
+}
+
 void launch_gemm_nt(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc, int M,
                     int N, int K, hipStream_t st) {
-    // pick the tile whose grid wastes the fewest CU-rounds (256 CUs)
-    auto rounds = [&](int bm, int bn) {
-        long t = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
-        long r = (t + 255) / 256;
-        return (double)r * bm * bn;             // cost ~ rounds * tile area
-    };
-    const bool narrow = N <= 64;
-    if (!narrow && rounds(128, 128) <= rounds(128, 64)) {
-        int tn = (N + 127) / 128, tm = (M + 127) / 128;
-        hipLaunchKernelGGL((gemm_nt_kernel<128, 128>), dim3(tn * tm), dim3(256), 0, st, A, lda, Bt, ldb, bias, C, ldc, M,
-                           N, K, tn, tn * tm);
-    } else {
-        int tn = (N + 63) / 64, tm = (M + 127) / 128;
-        hipLaunchKernelGGL((gemm_nt_kernel<128, 64>), dim3(tn * tm), dim3(256), 0, st, A, lda, Bt, ldb, bias, C, ldc, M,
-                           N, K, tn, tn * tm);
-    }
+    launch_gemm_nt_variant(A, lda, Bt, ldb, bias, C, ldc, M, N, K, 0, st);
 }
 
 // ---------------------------------------------------------------------------------

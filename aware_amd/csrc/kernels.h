@@ -70,6 +70,10 @@ void launch_finish(const float* yraw, const int* frame_off, const unsigned long 
 // C[M][N] = A[M][K] * Bt[N][K]^T (+ bias[N]); all row-major fp32, K % 4 == 0, 16-byte aligned rows
 void launch_gemm_nt(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc, int M,
                     int N, int K, hipStream_t st);
+void launch_gemm_nt_variant(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc,
+                            int M, int N, int K, int variant, hipStream_t st);
+int gemm_autotune(const float* A, int lda, const float* Bt, int ldb, float* C, int ldc, int M, int N, int K,
+                  hipStream_t st);
 // mel block: InstanceNorm over time, per-clip GlobalStandardize, AvgPool(2,2)
 void launch_mel_norm_fwd(const float* xm, const int* frame_off, const int* pool_off, float* x0, float* stats,
                          float* gstat, float* part, int pstride, int B, int max_frames, hipStream_t st);

@@ -179,6 +179,10 @@ int aware_gaussian_noise(const float* in, float* out, const int* off, const int*
 /* ---- bare GEMM (tests / roofline): C[M][N] = A[M][K] * Bt[N][K]^T + bias ------------------------------ */
 int aware_gemm_nt(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc,
                   int M, int N, int K, void* stream);
+/* same with an explicit tile configuration: variant 0 = automatic, 1..12 = fixed (tuning aid; all
+ * configurations produce bit-identical results) */
+int aware_gemm_nt_variant(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc,
+                          int M, int N, int K, int variant, void* stream);
 
 #ifdef __cplusplus
 }
