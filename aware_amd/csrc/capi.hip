@@ -91,7 +91,7 @@ extern "C" int aware_plan_create(aware_plan** out, int n_fft, int hop, int win_l
     const int nband = band_hi_bin - band_lo_bin + 1;
     if (band_lo_bin < 1 || band_hi_bin > 511 || nband < 1 || nband > kFS) return AWARE_E_UNSUPPORTED;
     const double PI = 3.14159265358979323846;
-    std::vector<float> h(2 * 512 + 2 * 512 + 1024 + 1024);
+    std::vector<float> h(2 * 512 + 2 * 512 + 1024 + 1024 + 3 * 768);
     float* tw512 = h.data();
     float* tw1024 = tw512 + 1024;
     float* win = tw1024 + 1024;
@@ -108,6 +108,19 @@ extern "C" int aware_plan_create(aware_plan** out, int n_fft, int hop, int win_l
         win[i] = (float)w;
         win2[i] = win[i] * win[i];
     }
+    // overlap-add envelope tables, summed in ascending frame order like ola_envelope_loop
+    float* env = win2 + 1024;
+    for (int q = 0; q < 768; ++q) {
+        float e = 0.f;
+        for (int t = 0; t <= (q >> 8); ++t) e += win2[q - 256 * t];
+        env[q] = e;                                               // head: p = q < 768
+        float ei = 0.f;
+        for (int off = (q & 255) + 768; off >= (q & 255); off -= 256) ei += win2[off];
+        env[768 + q] = ei;                                        // interior: p mod 256 = q & 255
+        float et = 0.f;
+        for (int off = (q & 255) + 768; off >= q + 256; off -= 256) et += win2[off];
+        env[1536 + q] = et;                                       // tail: p = 256*T + q
+    }
     aware_plan* p = new aware_plan();
     HIPCHK(hipMalloc(&p->mem, h.size() * sizeof(float)));
     HIPCHK(hipMemcpy(p->mem, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -116,6 +129,7 @@ extern "C" int aware_plan_create(aware_plan** out, int n_fft, int hop, int win_l
     p->dev.tw1024 = (const cf*)(d + 1024);
     p->dev.window = d + 2048;
     p->dev.window2 = d + 3072;
+    p->dev.env_tab = d + 4096;
     p->dev.band_lo = band_lo_bin;
     p->dev.nband = nband;
     *out = p;

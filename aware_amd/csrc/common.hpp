@@ -21,6 +21,7 @@ struct PlanDev {
     const cf* tw1024;     // exp(-2 pi i j/1024), j < 512
     const float* window;  // w[1024]
     const float* window2; // w^2[1024]
+    const float* env_tab; // overlap-add envelope: head[768], interior[768 (256 used)], tail[768]
     int band_lo;          // first band bin (32)
     int nband;            // number of band bins (225)
 };
@@ -90,8 +91,8 @@ __device__ __forceinline__ ClipNorm clip_norm_from_partials(const unsigned long 
     return c;
 }
 
-// sum of squared windows at padded position p for a clip of T frames
-__device__ __forceinline__ float ola_envelope(const float* __restrict__ w2, int p, int T) {
+// sum of squared windows at padded position p for a clip of T frames (reference loop form)
+__device__ __forceinline__ float ola_envelope_loop(const float* __restrict__ w2, int p, int T) {
     int thi = p >> 8;                    // floor(p/256)
     int tlo = thi - 3;
     if (tlo < 0) tlo = 0;
@@ -99,6 +100,16 @@ __device__ __forceinline__ float ola_envelope(const float* __restrict__ w2, int 
     float e = 0.f;
     for (int t = tlo; t <= thi; ++t) e += w2[p - kHop * t];
     return e;
+}
+
+// Same value from the plan's tables (built on the host with the same summation order): the
+// envelope only depends on p near the two ends of a clip and on p mod 256 in between.
+__device__ __forceinline__ float ola_envelope(const PlanDev& pl, int p, int T) {
+    if (T < 4) return ola_envelope_loop(pl.window2, p, T);
+    if (p < 768) return pl.env_tab[p];
+    const int q = p - kHop * T;
+    if (q >= 0) return pl.env_tab[1536 + q];
+    return pl.env_tab[768 + (p & 255)];
 }
 
 // balanced split of `nblk` hop blocks into nseg = ceil(nblk/13) segments

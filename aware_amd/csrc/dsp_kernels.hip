@@ -80,7 +80,7 @@ struct AnalysisArgs {
 };
 
 template <int MODE>
-__global__ __launch_bounds__(kThreads) void analysis_kernel(AnalysisArgs a) {
+__global__ __launch_bounds__(kThreads, 4) void analysis_kernel(AnalysisArgs a) {
     __shared__ float chunk[kChunk];
     __shared__ cf scratch[4][kFftScratch];
     __shared__ unsigned long long red[4];
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(kThreads) void analysis_kernel(AnalysisArgs a) {
                 float g = x[src];
                 if ((unsigned)src == kmax) g -= adot * smax;
                 g = g / (m * m2);
-                v = g / ola_envelope(a.plan.window2, p, T);
+                v = g / ola_envelope(a.plan, p, T);
             } else {
                 v = 0.f;
             }
@@ -165,8 +165,28 @@ __global__ __launch_bounds__(kThreads) void analysis_kernel(AnalysisArgs a) {
         improved = a.improved[b];
     }
 
+    // The adjoint epilogue reads six operands per bin that do not depend on the FFT: issue
+    // those loads before the transform so their latency hides behind it (bins of the band sit
+    // in registers r = 0..4 when band_lo < 64, the model card's case).
+    const bool pre_ok = (MODE == AN_ADJ) && a.do_step && band_lo < 64;
+#pragma unroll 1
     for (int fr = wave; fr < nfr; fr += 4) {
         cf v[8];
+        const size_t row = (size_t)(f0 + t0 + fr);
+        cf preP[5];
+        float preM[5], preV[5], preC[5], preL[5], preH[5];
+        if (MODE == AN_ADJ) {
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                const int f = lane + 64 * r - band_lo;
+                preP[r] = mk(0.f, 0.f); preM[r] = preV[r] = preC[r] = preL[r] = preH[r] = 0.f;
+                if (pre_ok && f >= 0 && f < nband) {
+                    const size_t idx = row * kFS + f;
+                    preP[r] = a.phasor[idx]; preM[r] = a.mom[idx]; preV[r] = a.vel[idx]; preC[r] = a.coef[idx];
+                    preL[r] = a.lo[idx]; preH[r] = a.hi[idx];
+                }
+            }
+        }
         const float2* c2 = reinterpret_cast<const float2*>(chunk + kHop * fr);
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -176,7 +196,6 @@ __global__ __launch_bounds__(kThreads) void analysis_kernel(AnalysisArgs a) {
         fft512_wave<-1>(lane, v, fc, s);
         rfft_split_store(lane, v, s);
         wave_sync();
-        const size_t row = (size_t)(f0 + t0 + fr);
         if (a.full) {
             cf* out = a.full + row * 520;
 #pragma unroll
@@ -205,18 +224,22 @@ __global__ __launch_bounds__(kThreads) void analysis_kernel(AnalysisArgs a) {
                     if (a.unit) a.unit[idx] = (mg > 0.f) ? mk(X.x / mg, X.y / mg) : mk(a.unit_default, 0.f);
                 } else {
                     // dL/dc = Re(G conj P) with G = (2/N) rfft(.)  [adjoint of irfft on interior bins]
-                    cf P = a.phasor[idx];
+                    const bool pre = pre_ok && r < 5;
+                    cf P = pre ? preP[r < 5 ? r : 0] : a.phasor[idx];
                     float g = (X.x * P.x + X.y * P.y) * (1.0f / 512.0f);
                     if (a.grad_out) a.grad_out[idx] = g;
                     if (a.do_step) {
                         // torch.optim.NAdam single-tensor step + clamp + best snapshot
-                        float mo = a.mom[idx], ve = a.vel[idx], p = a.coef[idx];
+                        float mo, ve, p, blo, bhi;
+                        if (pre) { mo = preM[r < 5 ? r : 0]; ve = preV[r < 5 ? r : 0]; p = preC[r < 5 ? r : 0];
+                                   blo = preL[r < 5 ? r : 0]; bhi = preH[r < 5 ? r : 0]; }
+                        else { mo = a.mom[idx]; ve = a.vel[idx]; p = a.coef[idx]; blo = a.lo[idx]; bhi = a.hi[idx]; }
                         mo = mo + a.hyp.x * (g - mo);                    // exp_avg.lerp_(grad, 1-beta1)
                         ve = ve * a.hyp.y + (a.hyp.z * g) * g;          // mul_(beta2).addcmul_(g, g, 1-beta2)
                         float den = sqrtf(ve / sc.z) + a.hyp.w;
                         p = p + (sc.x * g) / den;
                         p = p + (sc.y * mo) / den;
-                        p = fminf(fmaxf(p, a.lo[idx]), a.hi[idx]);
+                        p = fminf(fmaxf(p, blo), bhi);
                         a.mom[idx] = mo; a.vel[idx] = ve; a.coef[idx] = p;
                         if (improved) a.best[idx] = p;
                     }
@@ -250,7 +273,7 @@ struct SynthArgs {
 };
 
 template <int MODE>
-__global__ __launch_bounds__(kThreads) void synth_kernel(SynthArgs a) {
+__global__ __launch_bounds__(kThreads, 4) void synth_kernel(SynthArgs a) {
     __shared__ float ola[kChunk];
     __shared__ cf scratch[4][kFftScratch];
     __shared__ unsigned long long red[4];
@@ -299,12 +322,34 @@ __global__ __launch_bounds__(kThreads) void synth_kernel(SynthArgs a) {
     // 4 rounds; in round r wave w owns frame r + 4w: concurrently processed frames are
     // 4 hops = 1024 samples apart, so the overlap-add needs no atomics and its
     // summation order is fixed.
+    // Band inputs of one frame.  When the band lies inside bins 1..256 (the model card: 32..256)
+    // register slot r needs exactly one input bin: its own bin k = lane+64r for k <= 256, the
+    // partner bin 512-k otherwise (k = 256 is its own partner).  Those 3 floats per slot are
+    // prefetched: the loads for round r4+1 are issued before round r4's transform.
+    const bool full_in = (MODE == SY_FWD && a.full);
+    const bool compact = !full_in && band_lo >= 1 && band_lo + nband <= 257;
+    float inA[8];
+    cf inP[8];
+    auto load_band = [&](int fi) {
+        const size_t row = (size_t)(f0 + tlo + fi);
+        const float* A = a.amp + row * kFS;
+        const cf* P = a.ph + row * kFS;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int k = lane + 64 * r;
+            const int f = ((k <= 256) ? k : 512 - k) - band_lo;
+            inA[r] = 0.f; inP[r] = mk(0.f, 0.f);
+            if (f >= 0 && f < nband) { inA[r] = A[f]; inP[r] = P[f]; }
+        }
+    };
+    if (compact && 4 * wave < nfr) load_band(4 * wave);
+#pragma unroll 1
     for (int r4 = 0; r4 < 4; ++r4) {
         const int fi = r4 + 4 * wave;
         if (fi < nfr) {
             const size_t row = (size_t)(f0 + tlo + fi);
             cf v[8];
-            if (MODE == SY_FWD && a.full) {
+            if (full_in) {
                 const cf* X = a.full + row * 520;
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
@@ -313,6 +358,15 @@ __global__ __launch_bounds__(kThreads) void synth_kernel(SynthArgs a) {
                     if (k == 0) { xk.y = 0.f; xp.y = 0.f; }      // C2R ignores Im of DC / Nyquist
                     v[r] = irfft_merge_bin(k, xk, xp, a.plan.tw1024);
                 }
+            } else if (compact) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int k = lane + 64 * r;
+                    const cf x = mk(inA[r] * inP[r].x, inA[r] * inP[r].y);
+                    const cf z = mk(0.f, 0.f);
+                    v[r] = irfft_merge_bin(k, (k <= 256) ? x : z, (k >= 256) ? x : z, a.plan.tw1024);
+                }
+                if (r4 < 3 && fi + 1 < nfr) load_band(fi + 1);
             } else {
                 const float* A = a.amp + row * kFS;
                 const cf* P = a.ph + row * kFS;
@@ -348,7 +402,7 @@ __global__ __launch_bounds__(kThreads) void synth_kernel(SynthArgs a) {
         unsigned long long best = 0;
         for (int j = j0 + tid; j < j1; j += kThreads) {
             const int p = kHalf + j;
-            float v = ola[p - pbase] / ola_envelope(a.plan.window2, p, T);
+            float v = ola[p - pbase] / ola_envelope(a.plan, p, T);
             if (add) v += add[j];
             out[j] = v;
             best = umax64(best, pack_max(fabsf(v), (unsigned)j));
