@@ -79,8 +79,9 @@ struct AnalysisArgs {
     float4 hyp;                       // {1-beta1, beta2, 1-beta2, eps}
 };
 
-template <int MODE>
-__global__ __launch_bounds__(kThreads, 4) void analysis_kernel(AnalysisArgs a) {
+// FULLOUT: write the full one-sided spectrum (generic STFT plug-in) instead of the band outputs
+template <int MODE, bool FULLOUT>
+__global__ __launch_bounds__(kThreads) void analysis_kernel(AnalysisArgs a) {
     __shared__ float chunk[kChunk];
     __shared__ cf scratch[4][kFftScratch];
     __shared__ unsigned long long red[4];
@@ -196,13 +197,13 @@ __global__ __launch_bounds__(kThreads, 4) void analysis_kernel(AnalysisArgs a) {
         fft512_wave<-1>(lane, v, fc, s);
         rfft_split_store(lane, v, s);
         wave_sync();
-        if (a.full) {
+        if (FULLOUT) {
             cf* out = a.full + row * 520;
 #pragma unroll
             for (int r = 0; r < 8; ++r) out[lane + 64 * r] = rfft_split_bin(lane + 64 * r, v[r], s, a.plan.tw1024);
             if (lane == 0) out[512] = mk(rfft_split_nyquist(s), 0.f);
         }
-        if (a.mag || a.unit || MODE == AN_ADJ) {
+        if (!FULLOUT) {
             // band bins k = band_lo + f, f < nband (<= 256)
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
@@ -272,8 +273,9 @@ struct SynthArgs {
     double* pdot;                     // [B][pstride] partial sums of g2*y2 out
 };
 
-template <int MODE>
-__global__ __launch_bounds__(kThreads, 4) void synth_kernel(SynthArgs a) {
+// INP: 0 = full one-sided spectrum, 1 = band inside bins 1..256 (prefetched), 2 = any band
+template <int MODE, int INP>
+__global__ __launch_bounds__(kThreads) void synth_kernel(SynthArgs a) {
     __shared__ float ola[kChunk];
     __shared__ cf scratch[4][kFftScratch];
     __shared__ unsigned long long red[4];
@@ -326,8 +328,8 @@ __global__ __launch_bounds__(kThreads, 4) void synth_kernel(SynthArgs a) {
     // register slot r needs exactly one input bin: its own bin k = lane+64r for k <= 256, the
     // partner bin 512-k otherwise (k = 256 is its own partner).  Those 3 floats per slot are
     // prefetched: the loads for round r4+1 are issued before round r4's transform.
-    const bool full_in = (MODE == SY_FWD && a.full);
-    const bool compact = !full_in && band_lo >= 1 && band_lo + nband <= 257;
+    constexpr bool full_in = (INP == 0);
+    constexpr bool compact = (INP == 1);
     float inA[8];
     cf inP[8];
     auto load_band = [&](int fi) {
@@ -507,9 +509,11 @@ void launch_analysis(const AnalysisLaunch& L, hipStream_t st) {
     a.hyp = make_float4(L.hyp[0], L.hyp[1], L.hyp[2], L.hyp[3]);
     int nx = (L.max_frames + kFramesPerWG - 1) / kFramesPerWG;
     if (L.adjoint)
-        hipLaunchKernelGGL(analysis_kernel<AN_ADJ>, grid2(nx, L.B), dim3(kThreads), 0, st, a);
+        hipLaunchKernelGGL((analysis_kernel<AN_ADJ, false>), grid2(nx, L.B), dim3(kThreads), 0, st, a);
+    else if (L.full)
+        hipLaunchKernelGGL((analysis_kernel<AN_NORM, true>), grid2(nx, L.B), dim3(kThreads), 0, st, a);
     else
-        hipLaunchKernelGGL(analysis_kernel<AN_NORM>, grid2(nx, L.B), dim3(kThreads), 0, st, a);
+        hipLaunchKernelGGL((analysis_kernel<AN_NORM, false>), grid2(nx, L.B), dim3(kThreads), 0, st, a);
 }
 
 void launch_synth(const SynthLaunch& L, hipStream_t st) {
@@ -522,10 +526,16 @@ void launch_synth(const SynthLaunch& L, hipStream_t st) {
     int nblk = L.max_frames - 1;
     int nx = (nblk + kSynthBlocks - 1) / kSynthBlocks;
     if (nx < 1) nx = 1;
-    if (L.adjoint)
-        hipLaunchKernelGGL(synth_kernel<SY_ADJ>, grid2(nx, L.B), dim3(kThreads), 0, st, a);
-    else
-        hipLaunchKernelGGL(synth_kernel<SY_FWD>, grid2(nx, L.B), dim3(kThreads), 0, st, a);
+    const bool compact = L.plan.band_lo >= 1 && L.plan.band_lo + L.plan.nband <= 257;
+    if (L.adjoint) {
+        if (compact) hipLaunchKernelGGL((synth_kernel<SY_ADJ, 1>), grid2(nx, L.B), dim3(kThreads), 0, st, a);
+        else hipLaunchKernelGGL((synth_kernel<SY_ADJ, 2>), grid2(nx, L.B), dim3(kThreads), 0, st, a);
+    } else if (L.full) {
+        hipLaunchKernelGGL((synth_kernel<SY_FWD, 0>), grid2(nx, L.B), dim3(kThreads), 0, st, a);
+    } else {
+        if (compact) hipLaunchKernelGGL((synth_kernel<SY_FWD, 1>), grid2(nx, L.B), dim3(kThreads), 0, st, a);
+        else hipLaunchKernelGGL((synth_kernel<SY_FWD, 2>), grid2(nx, L.B), dim3(kThreads), 0, st, a);
+    }
 }
 
 void launch_embed_prepare(const float* c0, float* coef, float* lo, float* hi, float* mom, float* vel, float* best,
