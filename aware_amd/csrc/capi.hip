@@ -61,6 +61,7 @@ struct aware_batch {
     int B = 0;
     std::vector<int> n, in_off, T, frame_off, pool_off, out_off, out_len, pc_in, pc_syn;
     int NF = 0, NP = 0, NS = 0, max_frames = 0, max_len = 0, pstride = 0;
+    int uniform_tp = 0;   // pooled frames per clip when all clips agree (else 0)
     // device tables (one allocation)
     int* d_mem = nullptr;
     int *d_frame_off = nullptr, *d_pool_off = nullptr, *d_in_off = nullptr, *d_in_len = nullptr, *d_out_off = nullptr,
@@ -167,7 +168,7 @@ extern "C" int aware_batch_create(aware_batch** out, int B, const int* n_samples
         const int T = 1 + n / kHop;
         b->T[i] = T;
         b->frame_off[i + 1] = b->frame_off[i] + T;
-        b->pool_off[i + 1] = b->pool_off[i] + T / 2;
+        b->pool_off[i + 1] = b->pool_off[i] + ((T / 2 + 31) & ~31);   // pooled rows are 32-aligned per clip
         b->out_off[i] = kHop * (b->frame_off[i] - i);
         b->out_len[i] = kHop * (T - 1);
         b->pc_in[i] = (n + 4095) / 4096;
@@ -181,6 +182,9 @@ extern "C" int aware_batch_create(aware_batch** out, int B, const int* n_samples
     }
     b->NF = b->frame_off[B];
     b->NP = b->pool_off[B];
+    b->uniform_tp = b->T[0] / 2;
+    for (int i = 1; i < B; ++i)
+        if (b->T[i] / 2 != b->uniform_tp) b->uniform_tp = 0;
     b->NS = kHop * (b->NF - B);
     b->pstride = max_pc;
     const size_t ints = (size_t)(B + 1) * 2 + (size_t)B * 6;
@@ -383,6 +387,14 @@ static size_t det_bytes(const aware_batch* b, const aware_detector* d) {
     return f * sizeof(float) + 256 * (8 + 2 * d->n_layers);
 }
 
+// number of 32-row groups per clip when the fused clip-aligned GEMM applies (uniform batch,
+// at most 128 pooled rows per clip), else 0
+static int clip_tile_groups(const aware_batch* b) {
+    if (!b->uniform_tp) return 0;
+    const int g = (b->uniform_tp + 31) / 32;
+    return (g >= 1 && g <= 4) ? g : 0;
+}
+
 // forward through the network; mag [NF][256] -> act[last], pred
 static int det_forward(const aware_detector* d, const aware_batch* b, const float* mag, DetBufs& o, hipStream_t st) {
     launch_gemm_nt(mag, kFS, d->melT, kFS, nullptr, o.xm, 128, b->NF, 128, kFS, st);
@@ -391,12 +403,20 @@ static int det_forward(const aware_detector* d, const aware_batch* b, const floa
                         b->max_frames, st);
     LAUNCHCHK(); PROF(K_MELNORM);
     const float* x = o.x0;
+    const int nwm = clip_tile_groups(b);
     for (int l = 0; l < d->n_layers; ++l) {
         const int ci = d->ch[l], co = d->ch[l + 1];
-        launch_gemm_nt(x, ci, d->w[l], ci, d->bias[l], o.act[l], co, b->NP, co, ci, st);
-        LAUNCHCHK(); PROF(K_GEMM);
-        launch_in_lrelu_fwd(o.act[l], b->d_pool_off, o.rstd[l], co, b->B, b->max_frames / 2, st);
-        LAUNCHCHK(); PROF(K_INLRELU);
+        if (nwm && co >= 128) {
+            // conv + InstanceNorm + LeakyReLU in one kernel (clip-aligned tiles)
+            launch_gemm_clip(x, ci, d->w[l], ci, d->bias[l], o.act[l], co, b->B, nwm, b->uniform_tp, co, ci, 1, o.rstd[l],
+                             nullptr, st);
+            LAUNCHCHK(); PROF(K_GEMM);
+        } else {
+            launch_gemm_nt(x, ci, d->w[l], ci, d->bias[l], o.act[l], co, b->NP, co, ci, st);
+            LAUNCHCHK(); PROF(K_GEMM);
+            launch_in_lrelu_fwd(o.act[l], b->d_frame_off, b->d_pool_off, o.rstd[l], co, b->B, b->max_frames / 2, st);
+            LAUNCHCHK(); PROF(K_INLRELU);
+        }
         x = o.act[l];
     }
     return AWARE_OK;
@@ -417,7 +437,7 @@ extern "C" int aware_detector_forward(const aware_detector* d, const aware_batch
     if (!c.ok) return AWARE_E_WORKSPACE;
     int rc = det_forward(d, b, mag, o, st);
     if (rc) return rc;
-    launch_head(o.act[d->n_layers - 1], b->d_pool_off, nullptr, values, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
+    launch_head(o.act[d->n_layers - 1], b->d_frame_off, b->d_pool_off, nullptr, values, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
                 d->nbits, b->B, st);
     LAUNCHCHK();
     return AWARE_OK;
@@ -437,7 +457,7 @@ extern "C" int aware_detect(const aware_plan* plan, const aware_detector* d, con
     if (rc) return rc;
     rc = det_forward(d, b, mag, o, st);
     if (rc) return rc;
-    launch_head(o.act[d->n_layers - 1], b->d_pool_off, nullptr, values, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
+    launch_head(o.act[d->n_layers - 1], b->d_frame_off, b->d_pool_off, nullptr, values, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
                 d->nbits, b->B, st);
     LAUNCHCHK();
     return AWARE_OK;
@@ -631,15 +651,27 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
     // :109 loss, :120-122 best tracking, gradient seed
     float* dA = e->d1;
     float* dB = e->d2;
-    launch_head(e->db.act[nl - 1], b->d_pool_off, e->target, e->db.pred, e->loss, e->best_loss, e->improved, dA, e->step,
+    launch_head(e->db.act[nl - 1], b->d_frame_off, b->d_pool_off, e->target, e->db.pred, e->loss, e->best_loss, e->improved, dA, e->step,
                 e->cfg.loss, d->nbits, b->B, st);
     LAUNCHCHK(); PROF(K_HEAD);
     // :111 backward through the detector (data gradients only; weights are frozen :76-77)
+    const int nwm = clip_tile_groups(b);
+    bool dz_ready = false;      // dA already holds dL/dZ of layer l (fused into the producing GEMM)
     for (int l = nl - 1; l >= 0; --l) {
         const int ci = d->ch[l], co = d->ch[l + 1];
-        launch_in_lrelu_bwd(dA, e->db.act[l], b->d_pool_off, e->db.rstd[l], co, b->B, b->max_frames / 2, st);
-        LAUNCHCHK(); PROF(K_INLRELU);
-        launch_gemm_nt(dA, co, d->wT[l], co, nullptr, dB, ci, b->NP, ci, co, st);
+        if (!dz_ready) {
+            launch_in_lrelu_bwd(dA, e->db.act[l], b->d_frame_off, b->d_pool_off, e->db.rstd[l], co, b->B, b->max_frames / 2, st);
+            LAUNCHCHK(); PROF(K_INLRELU);
+        }
+        if (nwm && l > 0 && ci >= 128) {
+            // data-gradient GEMM whose epilogue is the backward of block l-1's InstanceNorm+LeakyReLU
+            launch_gemm_clip(dA, co, d->wT[l], co, nullptr, dB, ci, b->B, nwm, b->uniform_tp, ci, co, 2, e->db.rstd[l - 1],
+                             e->db.act[l - 1], st);
+            dz_ready = true;
+        } else {
+            launch_gemm_nt(dA, co, d->wT[l], co, nullptr, dB, ci, b->NP, ci, co, st);
+            dz_ready = false;
+        }
         LAUNCHCHK(); PROF(K_GEMM);
         float* t = dA; dA = dB; dB = t;
     }
@@ -841,7 +873,7 @@ extern "C" int aware_gaussian_noise(const float* in, float* out, const int* off,
 
 extern "C" int aware_gemm_nt_variant(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C,
                                      int ldc, int M, int N, int K, int variant, void* stream) {
-    if (!A || !Bt || !C || M < 1 || N < 1 || K < 4 || (K & 3) || (lda & 3) || (ldb & 3) || variant < 0 || variant > 12)
+    if (!A || !Bt || !C || M < 1 || N < 1 || K < 4 || (K & 3) || (lda & 3) || (ldb & 3) || variant < 0 || variant > 16)
         return AWARE_E_BADARG;
     launch_gemm_nt_variant(A, lda, Bt, ldb, bias, C, ldc, M, N, K, variant, (hipStream_t)stream);
     LAUNCHCHK();

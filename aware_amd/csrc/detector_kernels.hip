@@ -159,9 +159,204 @@ static void gemm_launch(const float* A, int lda, const float* Bt, int ldb, const
                        ldb, bias, C, ldc, M, N, K, tn, tn * tm);
 }
 
+// ---------------------------------------------------------------------------------
+// Clip-aligned GEMM with the conv block's tail fused into the epilogue.
+// Pooled rows are laid out 32-aligned per clip; for a uniform batch whose clips need
+// NWM <= 4 groups of 32 rows, one workgroup owns ALL rows of one clip for a 32*NWN-column
+// slab, so the per-(clip, channel) InstanceNorm statistics are complete inside the
+// workgroup:
+//   EPI_FWD: C = LeakyReLU_0.2((z - mean_t z) * rstd), z = acc + bias; rstd saved
+//            (modules/conv1d.py:38-42: conv -> InstanceNorm1d -> LeakyReLU)
+//   EPI_BWD: acc = dL/dA of the PREVIOUS block's output A (read here, post-activation);
+//            C = dL/dZ = rstd * (dU - mean_t dU - u * mean_t(dU*u)), dU = acc * lrelu'(u)
+// This removes the separate normalisation passes (one read + one write of the activation each).
+// Same main loop as gemm_nt_kernel, wave tile 32x32, BK = 32, one LDS buffer.
+// ---------------------------------------------------------------------------------
+enum { EPI_PLAIN = 0, EPI_FWD = 1, EPI_BWD = 2 };
+
+template <int NWM, int NWN, int EPI>
+__global__ __launch_bounds__(64 * NWM * NWN) void gemm_clip_kernel(const float* __restrict__ A, int lda,
+                                                                    const float* __restrict__ Bt, int ldb,
+                                                                    const float* __restrict__ bias, float* __restrict__ C,
+                                                                    int ldc, int Tp, int N, int K, int tiles_n, int ntiles,
+                                                                    float* __restrict__ rstd_io,
+                                                                    const float* __restrict__ act) {
+    constexpr int BM = 32 * NWM, BN = 32 * NWN, BK = 32;
+    constexpr int NT = 64 * NWM * NWN, LD = BK + 4, KQ = BK / 4;
+    constexpr int RPP = NT / KQ;
+    constexpr int LA = (BM + RPP - 1) / RPP, LB = (BN + RPP - 1) / RPP;
+    __shared__ float As[BM * LD];
+    __shared__ float Bs[BN * LD];
+    __shared__ float red1[NWM][BN], red2[NWM][BN];
+
+    int id = blockIdx.x;
+    if ((ntiles & 7) == 0) id = (id & 7) * (ntiles >> 3) + (id >> 3);
+    const int clip = id / tiles_n;
+    const int bm = clip * BM;
+    const int bn = (id % tiles_n) * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int li = lane & 31, lh = lane >> 5;
+    const int lrow = tid / KQ, lkq = (tid % KQ) * 4;
+
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+
+    float4 ra[LA], rb[LB];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            int rl = lrow + RPP * i, k = k0 + lkq;
+            ra[i] = (rl < BM && k < K) ? *reinterpret_cast<const float4*>(A + (size_t)(bm + rl) * lda + k) : make_float4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            int rl = lrow + RPP * i, r = bn + rl, k = k0 + lkq;
+            rb[i] = (rl < BN && r < N && k < K) ? *reinterpret_cast<const float4*>(Bt + (size_t)r * ldb + k) : make_float4(0, 0, 0, 0);
+        }
+    };
+    auto sstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < LA; ++i)
+            if (lrow + RPP * i < BM) *reinterpret_cast<float4*>(&As[(lrow + RPP * i) * LD + lkq]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < LB; ++i)
+            if (lrow + RPP * i < BN) *reinterpret_cast<float4*>(&Bs[(lrow + RPP * i) * LD + lkq]) = rb[i];
+    };
+    const int nk = (K + BK - 1) / BK;
+    gload(0);
+    sstore();
+    if (nk > 1) gload(BK);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
+            const float4 af = *reinterpret_cast<const float4*>(&As[(wm * 32 + li) * LD + 8 * g + 4 * lh]);
+            const float4 bf = *reinterpret_cast<const float4*>(&Bs[(wn * 32 + li) * LD + 8 * g + 4 * lh]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc, 0, 0, 0);
+        }
+        __syncthreads();
+        if (kt + 1 < nk) {
+            sstore();
+            if (kt + 2 < nk) gload((kt + 2) * BK);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: this wave holds rows wm*32 + (e&3) + 8*(e>>2) + 4*lh of column col ----
+    const int cl = wn * 32 + li;             // column inside the slab
+    const int col = bn + cl;
+    const bool cok = col < N;
+    const float invT = 1.0f / (float)Tp;
+    if (EPI == EPI_PLAIN) {
+        const float bv = (bias && cok) ? bias[col] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int r = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            if (cok) C[(size_t)(bm + r) * ldc + col] = (r < Tp) ? acc[e] + bv : 0.f;
+        }
+        return;
+    }
+    if (EPI == EPI_FWD) {
+        const float bv = (bias && cok) ? bias[col] : 0.f;
+        float z[16];
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int r = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            z[e] = acc[e] + bv;
+            if (r < Tp) s += z[e];
+        }
+        s += __shfl_xor(s, 32);
+        if (lh == 0) red1[wm][cl] = s;
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWM; ++w) tot += red1[w][cl];
+        const float mean = tot * invT;
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int r = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            if (r < Tp) { const float d = z[e] - mean; q += d * d; }
+        }
+        q += __shfl_xor(q, 32);
+        if (lh == 0) red2[wm][cl] = q;
+        __syncthreads();
+        float qt = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWM; ++w) qt += red2[w][cl];
+        const float rs = 1.0f / sqrtf(qt * invT + 1e-5f);
+        if (cok && wm == 0 && lh == 0) rstd_io[(size_t)clip * N + col] = rs;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int r = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            const float u = (z[e] - mean) * rs;
+            if (cok) C[(size_t)(bm + r) * ldc + col] = (r < Tp) ? (u > 0.f ? u : 0.2f * u) : 0.f;
+        }
+        return;
+    }
+    // EPI_BWD
+    {
+        const float rs = cok ? rstd_io[(size_t)clip * N + col] : 0.f;
+        float du[16], u[16];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int r = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            du[e] = 0.f; u[e] = 0.f;
+            if (cok && r < Tp) {
+                const float av = act[(size_t)(bm + r) * ldc + col];
+                u[e] = av > 0.f ? av : av * 5.0f;                 // invert LeakyReLU(0.2)
+                du[e] = acc[e] * (av > 0.f ? 1.f : 0.2f);
+            }
+            s1 += du[e]; s2 += du[e] * u[e];
+        }
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (lh == 0) { red1[wm][cl] = s1; red2[wm][cl] = s2; }
+        __syncthreads();
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWM; ++w) { t1 += red1[w][cl]; t2 += red2[w][cl]; }
+        const float m1 = t1 * invT, m2 = t2 * invT;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int r = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            if (cok) C[(size_t)(bm + r) * ldc + col] = (r < Tp) ? rs * (du[e] - m1 - u[e] * m2) : 0.f;
+        }
+    }
+}
+
+template <int NWM, int NWN, int EPI>
+static void clip_launch(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc, int B,
+                        int Tp, int N, int K, float* rstd_io, const float* act, hipStream_t st) {
+    const int tn = (N + 32 * NWN - 1) / (32 * NWN);
+    hipLaunchKernelGGL((gemm_clip_kernel<NWM, NWN, EPI>), dim3(tn * B), dim3(64 * NWM * NWN), 0, st, A, lda, Bt, ldb, bias, C,
+                       ldc, Tp, N, K, tn, tn * B, rstd_io, act);
+}
+
+// rows_per_clip = 32 * nwm (1..4).  epi: 0 plain, 1 forward IN+LeakyReLU, 2 backward of IN+LeakyReLU
+void launch_gemm_clip(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc, int B,
+                      int nwm, int Tp, int N, int K, int epi, float* rstd_io, const float* act, hipStream_t st) {
+#define CL(M_, E_) clip_launch<M_, 4, E_>(A, lda, Bt, ldb, bias, C, ldc, B, Tp, N, K, rstd_io, act, st)
+#define CLM(E_)                                                             \
+    switch (nwm) { case 1: CL(1, E_); break; case 2: CL(2, E_); break; case 3: CL(3, E_); break; default: CL(4, E_); break; }
+    if (epi == EPI_FWD) { CLM(EPI_FWD) }
+    else if (epi == EPI_BWD) { CLM(EPI_BWD) }
+    else { CLM(EPI_PLAIN) }
+#undef CLM
+#undef CL
+}
+
 // Tile configurations.  All of them accumulate k in the same order, so the result of a GEMM
 // is bit-identical whichever one runs: choosing by measurement does not change numerics.
-constexpr int kNumGemmVariants = 12;
+constexpr int kNumGemmVariants = 12;   // variants above this number are experiments, not auto-tuned
 static void gemm_dispatch(int variant, const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C,
                           int ldc, int M, int N, int K, hipStream_t st) {
 #define GL(...) gemm_launch<__VA_ARGS__>(A, lda, Bt, ldb, bias, C, ldc, M, N, K, st)
@@ -178,6 +373,10 @@ static void gemm_dispatch(int variant, const float* A, int lda, const float* Bt,
         case 10: GL(128, 64, 4, 2, 32, 1); break;
         case 11: GL(64, 128, 2, 4, 32, 1); break;
         case 12: GL(128, 128, 4, 4, 32, 1); break;
+        case 13: GL(96, 128, 3, 4, 32, 1); break;
+        case 14: GL(96, 128, 3, 4, 16, 2); break;
+        case 15: GL(96, 64, 3, 2, 16, 2); break;
+        case 16: GL(96, 256, 3, 4, 32, 1); break;
         default: GL(64, 64, 2, 2, 32, 1); break;
     }
 #undef GL
@@ -351,6 +550,9 @@ __global__ __launch_bounds__(256) void mel_apply_pool_kernel(const float* __rest
         float u1 = (x[(size_t)(2 * tp + 1) * 128] - mu) * rs;
         o[(size_t)tp * 128] = 0.5f * (u0 * ginv + u1 * ginv);
     }
+    // pooled rows are 32-aligned per clip: keep the pad rows finite (they flow through the GEMMs)
+    if ((int)blockIdx.x == nchunk - 1)
+        for (int tp = Tp + g; tp < ((Tp + 31) & ~31); tp += 2) o[(size_t)tp * 128] = 0.f;
 }
 
 // backward partials: D1_c = sum_t dv, D2_c = sum_t dv*u over the chunk (dv = dx0/2 on pooled frames)
@@ -424,11 +626,11 @@ __global__ __launch_bounds__(256) void mel_bwd_apply_kernel(const float* __restr
 // conv block tail: InstanceNorm1d over time (biased var, eps 1e-5) + LeakyReLU(0.2),
 // in place.  Workgroup = (64 channels) x (4 row groups) of one clip.
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void in_lrelu_fwd_kernel(float* __restrict__ z, const int* __restrict__ pool_off,
+__global__ __launch_bounds__(256) void in_lrelu_fwd_kernel(float* __restrict__ z, const int* __restrict__ frame_off, const int* __restrict__ pool_off,
                                                             float* __restrict__ rstd, int C) {
     __shared__ float s[4][64];
     const int b = blockIdx.y, c0 = blockIdx.x * 64;
-    const int r0 = pool_off[b], Tp = pool_off[b + 1] - r0;
+    const int r0 = pool_off[b], Tp = (frame_off[b + 1] - frame_off[b]) / 2;   // rows are 32-aligned per clip
     const int cl = threadIdx.x & 63, g = threadIdx.x >> 6, c = c0 + cl;
     if (Tp <= 0) return;
     const bool ok = c < C;
@@ -454,11 +656,11 @@ __global__ __launch_bounds__(256) void in_lrelu_fwd_kernel(float* __restrict__ z
 // Register-resident variants for clips of up to 4*R pooled frames (R rows per thread): the
 // activation is read once and written once.
 template <int R>
-__global__ __launch_bounds__(256) void in_lrelu_fwd_reg_kernel(float* __restrict__ z, const int* __restrict__ pool_off,
+__global__ __launch_bounds__(256) void in_lrelu_fwd_reg_kernel(float* __restrict__ z, const int* __restrict__ frame_off, const int* __restrict__ pool_off,
                                                                 float* __restrict__ rstd, int C) {
     __shared__ float s[4][64];
     const int b = blockIdx.y, c0 = blockIdx.x * 64;
-    const int r0 = pool_off[b], Tp = pool_off[b + 1] - r0;
+    const int r0 = pool_off[b], Tp = (frame_off[b + 1] - frame_off[b]) / 2;   // rows are 32-aligned per clip
     const int cl = threadIdx.x & 63, g = threadIdx.x >> 6, c = c0 + cl;
     if (Tp <= 0) return;
     const bool ok = c < C;
@@ -497,11 +699,11 @@ __global__ __launch_bounds__(256) void in_lrelu_fwd_reg_kernel(float* __restrict
 
 template <int R>
 __global__ __launch_bounds__(256) void in_lrelu_bwd_reg_kernel(float* __restrict__ dA, const float* __restrict__ A,
-                                                                const int* __restrict__ pool_off, const float* __restrict__ rstd,
+                                                                const int* __restrict__ frame_off, const int* __restrict__ pool_off, const float* __restrict__ rstd,
                                                                 int C) {
     __shared__ float s1[4][64], s2[4][64];
     const int b = blockIdx.y, c0 = blockIdx.x * 64;
-    const int r0 = pool_off[b], Tp = pool_off[b + 1] - r0;
+    const int r0 = pool_off[b], Tp = (frame_off[b + 1] - frame_off[b]) / 2;   // rows are 32-aligned per clip
     const int cl = threadIdx.x & 63, g = threadIdx.x >> 6, c = c0 + cl;
     if (Tp <= 0) return;
     const bool ok = c < C;
@@ -533,11 +735,11 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_reg_kernel(float* __restrict
 }
 
 __global__ __launch_bounds__(256) void in_lrelu_bwd_kernel(float* __restrict__ dA, const float* __restrict__ A,
-                                                            const int* __restrict__ pool_off, const float* __restrict__ rstd,
+                                                            const int* __restrict__ frame_off, const int* __restrict__ pool_off, const float* __restrict__ rstd,
                                                             int C) {
     __shared__ float s1[4][64], s2[4][64];
     const int b = blockIdx.y, c0 = blockIdx.x * 64;
-    const int r0 = pool_off[b], Tp = pool_off[b + 1] - r0;
+    const int r0 = pool_off[b], Tp = (frame_off[b + 1] - frame_off[b]) / 2;   // rows are 32-aligned per clip
     const int cl = threadIdx.x & 63, g = threadIdx.x >> 6, c = c0 + cl;
     if (Tp <= 0) return;
     const bool ok = c < C;
@@ -568,14 +770,14 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_kernel(float* __restrict__ d
 // loss_kind: 0 push_extremes, 1 mse, 2 hinge, 3 sign  (embedding/losses.py)
 // If dA3 == nullptr only the prediction is produced (detect path).
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ a3, const int* __restrict__ pool_off,
+__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ a3, const int* __restrict__ frame_off, const int* __restrict__ pool_off,
                                                     const float* __restrict__ target, float* __restrict__ pred,
                                                     float* __restrict__ loss_out, float* __restrict__ best_loss,
                                                     int* __restrict__ improved, float* __restrict__ dA3, int loss_kind,
                                                     int nbits) {
     __shared__ float part[4][64], mean[64], dm[64];
     const int b = blockIdx.x, c = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int r0 = pool_off[b], Tp = pool_off[b + 1] - r0;
+    const int r0 = pool_off[b], Tp = (frame_off[b + 1] - frame_off[b]) / 2;   // rows are 32-aligned per clip
     const int C = 2 * nbits;
     float m = 0.f;
     if (c < C)
@@ -647,23 +849,23 @@ void launch_mel_norm_bwd(const float* dx0, float* xm, const int* frame_off, cons
     hipLaunchKernelGGL(mel_bwd_apply_kernel, dim3(nx, B), dim3(256), 0, st, dx0, xm, frame_off, pool_off, stats, gstat, part,
                        pstride);
 }
-void launch_in_lrelu_fwd(float* z, const int* pool_off, float* rstd, int C, int B, int max_pooled, hipStream_t st) {
+void launch_in_lrelu_fwd(float* z, const int* frame_off, const int* pool_off, float* rstd, int C, int B, int max_pooled, hipStream_t st) {
     if (max_pooled <= 128)
-        hipLaunchKernelGGL(in_lrelu_fwd_reg_kernel<32>, dim3((C + 63) / 64, B), dim3(256), 0, st, z, pool_off, rstd, C);
+        hipLaunchKernelGGL(in_lrelu_fwd_reg_kernel<32>, dim3((C + 63) / 64, B), dim3(256), 0, st, z, frame_off, pool_off, rstd, C);
     else
-        hipLaunchKernelGGL(in_lrelu_fwd_kernel, dim3((C + 63) / 64, B), dim3(256), 0, st, z, pool_off, rstd, C);
+        hipLaunchKernelGGL(in_lrelu_fwd_kernel, dim3((C + 63) / 64, B), dim3(256), 0, st, z, frame_off, pool_off, rstd, C);
 }
-void launch_in_lrelu_bwd(float* dA, const float* A, const int* pool_off, const float* rstd, int C, int B,
+void launch_in_lrelu_bwd(float* dA, const float* A, const int* frame_off, const int* pool_off, const float* rstd, int C, int B,
                          int max_pooled, hipStream_t st) {
     if (max_pooled <= 128)
-        hipLaunchKernelGGL(in_lrelu_bwd_reg_kernel<32>, dim3((C + 63) / 64, B), dim3(256), 0, st, dA, A, pool_off, rstd, C);
+        hipLaunchKernelGGL(in_lrelu_bwd_reg_kernel<32>, dim3((C + 63) / 64, B), dim3(256), 0, st, dA, A, frame_off, pool_off, rstd, C);
     else
-        hipLaunchKernelGGL(in_lrelu_bwd_kernel, dim3((C + 63) / 64, B), dim3(256), 0, st, dA, A, pool_off, rstd, C);
+        hipLaunchKernelGGL(in_lrelu_bwd_kernel, dim3((C + 63) / 64, B), dim3(256), 0, st, dA, A, frame_off, pool_off, rstd, C);
 }
-void launch_head(const float* a3, const int* pool_off, const float* target, float* pred, float* loss,
+void launch_head(const float* a3, const int* frame_off, const int* pool_off, const float* target, float* pred, float* loss,
                  float* best_loss, int* improved, float* dA3, int* step, int loss_kind, int nbits, int B,
                  hipStream_t st) {
-    hipLaunchKernelGGL(head_kernel, dim3(B), dim3(256), 0, st, a3, pool_off, target, pred, loss, best_loss, improved, dA3,
+    hipLaunchKernelGGL(head_kernel, dim3(B), dim3(256), 0, st, a3, frame_off, pool_off, target, pred, loss, best_loss, improved, dA3,
                        loss_kind, nbits);
     (void)step;
 }

@@ -74,18 +74,22 @@ void launch_gemm_nt_variant(const float* A, int lda, const float* Bt, int ldb, c
                             int M, int N, int K, int variant, hipStream_t st);
 int gemm_autotune(const float* A, int lda, const float* Bt, int ldb, float* C, int ldc, int M, int N, int K,
                   hipStream_t st);
+// clip-aligned GEMM with fused InstanceNorm+LeakyReLU epilogues (uniform batches, <= 128 pooled rows per clip)
+void launch_gemm_clip(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc, int B,
+                      int nwm, int Tp, int N, int K, int epi, float* rstd_io, const float* act, hipStream_t st);
 // mel block: InstanceNorm over time, per-clip GlobalStandardize, AvgPool(2,2)
 void launch_mel_norm_fwd(const float* xm, const int* frame_off, const int* pool_off, float* x0, float* stats,
                          float* gstat, float* part, int pstride, int B, int max_frames, hipStream_t st);
 void launch_mel_norm_bwd(const float* dx0, float* xm_inout, const int* frame_off, const int* pool_off, const float* stats,
                          const float* gstat, float* part, int pstride, int B, int max_frames, hipStream_t st);
 // conv block tail: InstanceNorm over time + LeakyReLU(0.2), in place; saves rstd
-void launch_in_lrelu_fwd(float* z, const int* pool_off, float* rstd, int C, int B, int max_pooled, hipStream_t st);
+void launch_in_lrelu_fwd(float* z, const int* frame_off, const int* pool_off, float* rstd, int C, int B, int max_pooled,
+                         hipStream_t st);
 // backward of the same, in place on dA (A is the post-activation output of the forward)
-void launch_in_lrelu_bwd(float* dA, const float* A, const int* pool_off, const float* rstd, int C, int B,
+void launch_in_lrelu_bwd(float* dA, const float* A, const int* frame_off, const int* pool_off, const float* rstd, int C, int B,
                          int max_pooled, hipStream_t st);
 // BRH + loss + dL/dA3; also best-loss tracking
-void launch_head(const float* a3, const int* pool_off, const float* target, float* pred, float* loss,
+void launch_head(const float* a3, const int* frame_off, const int* pool_off, const float* target, float* pred, float* loss,
                  float* best_loss, int* improved, float* dA3, int* step, int loss_kind, int nbits, int B,
                  hipStream_t st);
 void launch_advance_step(int* step, hipStream_t st);
