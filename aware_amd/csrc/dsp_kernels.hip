@@ -148,7 +148,7 @@ __global__ __launch_bounds__(kThreads) void analysis_kernel(AnalysisArgs a) {
     __syncthreads();
 
     // ---- per-wave FFTs ---------------------------------------------------------------
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // wave index is wave-uniform: keep it scalar
     cf* s = scratch[wave];
     FftLaneConst fc;
     fft_lane_const(lane, a.plan.tw512, fc);
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(kThreads) void synth_kernel(SynthArgs a) {
     synth_segment(nblk, blockIdx.x, nseg, jb0, jb1);
     if ((int)blockIdx.x >= nseg || T < 1) return;
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // wave index is wave-uniform: keep it scalar
 
     // frames that touch the padded range this workgroup needs
     int tlo = max(0, jb0 - 1);
@@ -311,14 +311,9 @@ __global__ __launch_bounds__(kThreads) void synth_kernel(SynthArgs a) {
     cf* s = scratch[wave];
     FftLaneConst fc;
     fft_lane_const(lane, a.plan.tw512, fc);
-    float wr[16];
     // irfft's 1/1024 (1/2 in the merge, 1/512 here); the adjoint of the forward rfft is 512*irfft
     const float scale = (MODE == SY_FWD) ? (1.0f / 512.0f) : 1.0f;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        wr[2 * r] = a.plan.window[2 * (lane + 64 * r)] * scale;
-        wr[2 * r + 1] = a.plan.window[2 * (lane + 64 * r) + 1] * scale;
-    }
+    const float2* win2p = reinterpret_cast<const float2*>(a.plan.window);   // 4 KB, L1-resident
     const int band_lo = a.plan.band_lo, nband = a.plan.nband;
 
     // 4 rounds; in round r wave w owns frame r + 4w: concurrently processed frames are
@@ -338,10 +333,14 @@ __global__ __launch_bounds__(kThreads) void synth_kernel(SynthArgs a) {
         const cf* P = a.ph + row * kFS;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
+            // unconditional loads from a clamped index (the row always has kFS entries); bins
+            // outside the band are zeroed by the amplitude
             const int k = lane + 64 * r;
             const int f = ((k <= 256) ? k : 512 - k) - band_lo;
-            inA[r] = 0.f; inP[r] = mk(0.f, 0.f);
-            if (f >= 0 && f < nband) { inA[r] = A[f]; inP[r] = P[f]; }
+            const int fc_ = min(max(f, 0), kFS - 1);
+            const float am = A[fc_];
+            inP[r] = P[fc_];
+            inA[r] = (f >= 0 && f < nband) ? am : 0.f;
         }
     };
     if (compact && 4 * wave < nfr) load_band(4 * wave);
@@ -387,8 +386,9 @@ __global__ __launch_bounds__(kThreads) void synth_kernel(SynthArgs a) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 float2 q = o2[lane + 64 * r];
-                q.x += v[r].x * wr[2 * r];
-                q.y += v[r].y * wr[2 * r + 1];
+                const float2 w = win2p[lane + 64 * r];
+                q.x += v[r].x * (w.x * scale);
+                q.y += v[r].y * (w.y * scale);
                 o2[lane + 64 * r] = q;
             }
         }
