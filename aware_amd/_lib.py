@@ -53,6 +53,7 @@ _pi = C.POINTER(C.c_int)
 SIGNATURES = {
     "aware_version": (_i, []),
     "aware_last_hip_error": (C.c_char_p, []),
+    "aware_tune": (_i, [_i, _i]),
     "aware_plan_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i, _i]),
     "aware_plan_destroy": (None, [_vp]),
     "aware_batch_create": (_i, [C.POINTER(_vp), _i, _pi, _pi]),

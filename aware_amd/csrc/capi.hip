@@ -81,6 +81,11 @@ struct aware_detector {
 };
 
 extern "C" int aware_version(void) { return 100; }
+// tuning knob (not part of the drop-in surface): K-tile / buffering of the clip-aligned GEMM
+extern "C" int aware_tune(int key, int value) {
+    if (key == 1) { set_gemm_clip_config(value); return AWARE_OK; }
+    return AWARE_E_BADARG;
+}
 extern "C" const char* aware_last_hip_error(void) { return g_last_err.c_str(); }
 
 // ---------------------------------------------------------------------------------------------
@@ -366,7 +371,10 @@ struct DetBufs {
     float *mstats, *gstat, *mpart;   // mel statistics [B][128][4], [B][4], chunk partials
     int mstride;
     float* pred;      // [B][nbits]
+    float* zpart;     // split-K partial slabs of the last conv [kTailSplit][NP][C_last]
+    int tail;         // 1: the last conv was left as partials for the fused tail kernel
 };
+constexpr int kTailSplit = 4;
 static void carve_det(Carver& c, const aware_batch* b, const aware_detector* d, DetBufs& o) {
     o.xm = c.take<float>((size_t)b->NF * 128);
     o.x0 = c.take<float>((size_t)b->NP * 128);
@@ -379,11 +387,14 @@ static void carve_det(Carver& c, const aware_batch* b, const aware_detector* d, 
     o.mstride = (b->max_frames + 31) / 32;
     o.mpart = c.take<float>((size_t)b->B * o.mstride * 256);
     o.pred = c.take<float>((size_t)b->B * d->nbits);
+    o.zpart = c.take<float>((size_t)kTailSplit * b->NP * d->ch[d->n_layers]);
+    o.tail = 0;
 }
 static size_t det_bytes(const aware_batch* b, const aware_detector* d) {
     size_t f = (size_t)b->NF * 128 + (size_t)b->NP * 128 + (size_t)b->B * (128 * 4 + 4 + d->nbits) +
                (size_t)b->B * ((b->max_frames + 31) / 32) * 256;
     for (int l = 0; l < d->n_layers; ++l) f += (size_t)(b->NP + b->B) * d->ch[l + 1];
+    f += (size_t)kTailSplit * b->NP * d->ch[d->n_layers];
     return f * sizeof(float) + 256 * (8 + 2 * d->n_layers);
 }
 
@@ -404,9 +415,15 @@ static int det_forward(const aware_detector* d, const aware_batch* b, const floa
     LAUNCHCHK(); PROF(K_MELNORM);
     const float* x = o.x0;
     const int nwm = clip_tile_groups(b);
+    o.tail = 0;
     for (int l = 0; l < d->n_layers; ++l) {
         const int ci = d->ch[l], co = d->ch[l + 1];
-        if (nwm && co >= 128) {
+        if (l == d->n_layers - 1 && co <= 64 && b->max_frames / 2 <= 128) {
+            // skinny last conv: split-K partial slabs, summed inside the fused tail kernel
+            launch_gemm_nt_splitk(x, ci, d->w[l], ci, o.zpart, co, b->NP, co, ci, kTailSplit, st);
+            LAUNCHCHK(); PROF(K_GEMM);
+            o.tail = 1;
+        } else if (nwm && co >= 128) {
             // conv + InstanceNorm + LeakyReLU in one kernel (clip-aligned tiles)
             launch_gemm_clip(x, ci, d->w[l], ci, d->bias[l], o.act[l], co, b->B, nwm, b->uniform_tp, co, ci, 1, o.rstd[l],
                              nullptr, st);
@@ -437,8 +454,12 @@ extern "C" int aware_detector_forward(const aware_detector* d, const aware_batch
     if (!c.ok) return AWARE_E_WORKSPACE;
     int rc = det_forward(d, b, mag, o, st);
     if (rc) return rc;
-    launch_head(o.act[d->n_layers - 1], b->d_frame_off, b->d_pool_off, nullptr, values, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
-                d->nbits, b->B, st);
+    if (o.tail)
+        launch_tail(o.zpart, kTailSplit, (size_t)b->NP * d->ch[d->n_layers], d->bias[d->n_layers - 1], b->d_frame_off,
+                    b->d_pool_off, nullptr, values, nullptr, nullptr, nullptr, nullptr, nullptr, 0, d->nbits, b->B, st);
+    else
+        launch_head(o.act[d->n_layers - 1], b->d_frame_off, b->d_pool_off, nullptr, values, nullptr, nullptr, nullptr,
+                    nullptr, nullptr, 0, d->nbits, b->B, st);
     LAUNCHCHK();
     return AWARE_OK;
 }
@@ -457,8 +478,12 @@ extern "C" int aware_detect(const aware_plan* plan, const aware_detector* d, con
     if (rc) return rc;
     rc = det_forward(d, b, mag, o, st);
     if (rc) return rc;
-    launch_head(o.act[d->n_layers - 1], b->d_frame_off, b->d_pool_off, nullptr, values, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
-                d->nbits, b->B, st);
+    if (o.tail)
+        launch_tail(o.zpart, kTailSplit, (size_t)b->NP * d->ch[d->n_layers], d->bias[d->n_layers - 1], b->d_frame_off,
+                    b->d_pool_off, nullptr, values, nullptr, nullptr, nullptr, nullptr, nullptr, 0, d->nbits, b->B, st);
+    else
+        launch_head(o.act[d->n_layers - 1], b->d_frame_off, b->d_pool_off, nullptr, values, nullptr, nullptr, nullptr,
+                    nullptr, nullptr, 0, d->nbits, b->B, st);
     LAUNCHCHK();
     return AWARE_OK;
 }
@@ -651,12 +676,19 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
     // :109 loss, :120-122 best tracking, gradient seed
     float* dA = e->d1;
     float* dB = e->d2;
-    launch_head(e->db.act[nl - 1], b->d_frame_off, b->d_pool_off, e->target, e->db.pred, e->loss, e->best_loss, e->improved, dA, e->step,
-                e->cfg.loss, d->nbits, b->B, st);
+    int* step_ptr = do_step ? e->step : nullptr;        // the read-out kernel advances the step counter
+    bool dz_ready = false;      // dA already holds dL/dZ of layer l (fused into the producing kernel)
+    if (e->db.tail) {
+        launch_tail(e->db.zpart, kTailSplit, (size_t)b->NP * d->ch[nl], d->bias[nl - 1], b->d_frame_off, b->d_pool_off,
+                    e->target, e->db.pred, e->loss, e->best_loss, e->improved, dA, step_ptr, e->cfg.loss, d->nbits, b->B, st);
+        dz_ready = true;
+    } else {
+        launch_head(e->db.act[nl - 1], b->d_frame_off, b->d_pool_off, e->target, e->db.pred, e->loss, e->best_loss,
+                    e->improved, dA, step_ptr, e->cfg.loss, d->nbits, b->B, st);
+    }
     LAUNCHCHK(); PROF(K_HEAD);
     // :111 backward through the detector (data gradients only; weights are frozen :76-77)
     const int nwm = clip_tile_groups(b);
-    bool dz_ready = false;      // dA already holds dL/dZ of layer l (fused into the producing GEMM)
     for (int l = nl - 1; l >= 0; --l) {
         const int ci = d->ch[l], co = d->ch[l + 1];
         if (!dz_ready) {
@@ -698,10 +730,6 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
     memcpy(LA.hyp, e->hyp, sizeof(LA.hyp));
     launch_analysis(LA, st);
     LAUNCHCHK(); PROF(K_ANALYSIS_ADJ);
-    if (do_step) {
-        launch_advance_step(e->step, st);
-        LAUNCHCHK(); PROF(K_MISC);
-    }
     return AWARE_OK;
 }
 

@@ -34,7 +34,8 @@ template <int BM, int BN, int NWM, int NWN, int BK, int DB>
 __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(const float* __restrict__ A, int lda,
                                                                   const float* __restrict__ Bt, int ldb,
                                                                   const float* __restrict__ bias, float* __restrict__ C,
-                                                                  int ldc, int M, int N, int K, int tiles_n, int ntiles) {
+                                                                  int ldc, int M, int N, int K, int tiles_n, int ntiles,
+                                                                  int kchunk) {
     constexpr int NT = 64 * NWM * NWN, LD = BK + 4, KQ = BK / 4;
     constexpr int WM = BM / NWM, WN = BN / NWN, TM = WM / 32, TN = WN / 32;
     constexpr int RPP = NT / KQ;                       // rows covered by one pass of float4 loads
@@ -108,10 +109,15 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(const float* __
         }
     };
 
-    const int nk = (K + BK - 1) / BK;
-    gload(0);
+    // split-K: blockIdx.y owns k in [kbeg, kend) and writes its own partial slab C + y*M*ldc
+    const int kbeg = blockIdx.y * kchunk;
+    const int kend = min(K, kbeg + kchunk);
+    K = kend;                                            // the loaders zero-fill beyond K
+    C += (size_t)blockIdx.y * M * ldc;
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    gload(kbeg);
     sstore(0);
-    if (nk > 1) gload(BK);
+    if (nk > 1) gload(kbeg + BK);
     __syncthreads();
     if (DB == 2) {
         for (int kt = 0; kt < nk; ++kt) {
@@ -121,7 +127,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(const float* __
                 // buffer cur^1 was last read in iteration kt-1, which every wave left through the
                 // barrier below; the registers hold tile kt+1
                 sstore(cur ^ 1);
-                if (kt + 2 < nk) gload((kt + 2) * BK);
+                if (kt + 2 < nk) gload(kbeg + (kt + 2) * BK);
             }
             __syncthreads();
         }
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(const float* __
             __syncthreads();
             if (kt + 1 < nk) {
                 sstore(0);
-                if (kt + 2 < nk) gload((kt + 2) * BK);
+                if (kt + 2 < nk) gload(kbeg + (kt + 2) * BK);
                 __syncthreads();
             }
         }
@@ -153,10 +159,17 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(const float* __
 
 template <int BM, int BN, int NWM, int NWN, int BK, int DB>
 static void gemm_launch(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc, int M,
-                        int N, int K, hipStream_t st) {
+                        int N, int K, hipStream_t st, int ksplit = 1) {
     int tn = (N + BN - 1) / BN, tm = (M + BM - 1) / BM;
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, NWM, NWN, BK, DB>), dim3(tn * tm), dim3(64 * NWM * NWN), 0, st, A, lda, Bt,
-                       ldb, bias, C, ldc, M, N, K, tn, tn * tm);
+    int kchunk = ((K + ksplit - 1) / ksplit + BK - 1) / BK * BK;
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, NWM, NWN, BK, DB>), dim3(tn * tm, ksplit), dim3(64 * NWM * NWN), 0, st, A, lda,
+                       Bt, ldb, bias, C, ldc, M, N, K, tn, tn * tm, kchunk);
+}
+
+// split-K variant for skinny outputs (N <= 64): ksplit partial slabs C[z][M][ldc], no bias
+void launch_gemm_nt_splitk(const float* A, int lda, const float* Bt, int ldb, float* Cpart, int ldc, int M, int N, int K,
+                           int ksplit, hipStream_t st) {
+    gemm_launch<64, 64, 2, 2, 32, 1>(A, lda, Bt, ldb, nullptr, Cpart, ldc, M, N, K, st, ksplit);
 }
 
 // ---------------------------------------------------------------------------------
@@ -174,19 +187,19 @@ static void gemm_launch(const float* A, int lda, const float* Bt, int ldb, const
 // ---------------------------------------------------------------------------------
 enum { EPI_PLAIN = 0, EPI_FWD = 1, EPI_BWD = 2 };
 
-template <int NWM, int NWN, int EPI>
+template <int NWM, int NWN, int EPI, int BK, int DB>
 __global__ __launch_bounds__(64 * NWM * NWN) void gemm_clip_kernel(const float* __restrict__ A, int lda,
                                                                     const float* __restrict__ Bt, int ldb,
                                                                     const float* __restrict__ bias, float* __restrict__ C,
                                                                     int ldc, int Tp, int N, int K, int tiles_n, int ntiles,
                                                                     float* __restrict__ rstd_io,
                                                                     const float* __restrict__ act) {
-    constexpr int BM = 32 * NWM, BN = 32 * NWN, BK = 32;
+    constexpr int BM = 32 * NWM, BN = 32 * NWN;
     constexpr int NT = 64 * NWM * NWN, LD = BK + 4, KQ = BK / 4;
     constexpr int RPP = NT / KQ;
     constexpr int LA = (BM + RPP - 1) / RPP, LB = (BN + RPP - 1) / RPP;
-    __shared__ float As[BM * LD];
-    __shared__ float Bs[BN * LD];
+    __shared__ float As[DB][BM * LD];
+    __shared__ float Bs[DB][BN * LD];
     __shared__ float red1[NWM][BN], red2[NWM][BN];
 
     int id = blockIdx.x;
@@ -217,34 +230,49 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_clip_kernel(const float* 
             rb[i] = (rl < BN && r < N && k < K) ? *reinterpret_cast<const float4*>(Bt + (size_t)r * ldb + k) : make_float4(0, 0, 0, 0);
         }
     };
-    auto sstore = [&]() {
+    auto sstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < LA; ++i)
-            if (lrow + RPP * i < BM) *reinterpret_cast<float4*>(&As[(lrow + RPP * i) * LD + lkq]) = ra[i];
+            if (lrow + RPP * i < BM) *reinterpret_cast<float4*>(&As[buf][(lrow + RPP * i) * LD + lkq]) = ra[i];
 #pragma unroll
         for (int i = 0; i < LB; ++i)
-            if (lrow + RPP * i < BN) *reinterpret_cast<float4*>(&Bs[(lrow + RPP * i) * LD + lkq]) = rb[i];
+            if (lrow + RPP * i < BN) *reinterpret_cast<float4*>(&Bs[buf][(lrow + RPP * i) * LD + lkq]) = rb[i];
     };
-    const int nk = (K + BK - 1) / BK;
-    gload(0);
-    sstore();
-    if (nk > 1) gload(BK);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
+    auto compute = [&](int buf) {
 #pragma unroll
         for (int g = 0; g < BK / 8; ++g) {
-            const float4 af = *reinterpret_cast<const float4*>(&As[(wm * 32 + li) * LD + 8 * g + 4 * lh]);
-            const float4 bf = *reinterpret_cast<const float4*>(&Bs[(wn * 32 + li) * LD + 8 * g + 4 * lh]);
+            const float4 af = *reinterpret_cast<const float4*>(&As[buf][(wm * 32 + li) * LD + 8 * g + 4 * lh]);
+            const float4 bf = *reinterpret_cast<const float4*>(&Bs[buf][(wn * 32 + li) * LD + 8 * g + 4 * lh]);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc, 0, 0, 0);
         }
-        __syncthreads();
-        if (kt + 1 < nk) {
-            sstore();
-            if (kt + 2 < nk) gload((kt + 2) * BK);
+    };
+    const int nk = (K + BK - 1) / BK;
+    gload(0);
+    sstore(0);
+    if (nk > 1) gload(BK);
+    __syncthreads();
+    if (DB == 2) {
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            compute(cur);
+            if (kt + 1 < nk) {
+                sstore(cur ^ 1);
+                if (kt + 2 < nk) gload((kt + 2) * BK);
+            }
             __syncthreads();
+        }
+    } else {
+        for (int kt = 0; kt < nk; ++kt) {
+            compute(0);
+            __syncthreads();
+            if (kt + 1 < nk) {
+                sstore(0);
+                if (kt + 2 < nk) gload((kt + 2) * BK);
+                __syncthreads();
+            }
         }
     }
 
@@ -333,23 +361,32 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_clip_kernel(const float* 
     }
 }
 
-template <int NWM, int NWN, int EPI>
+template <int NWM, int NWN, int EPI, int BK, int DB>
 static void clip_launch(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc, int B,
                         int Tp, int N, int K, float* rstd_io, const float* act, hipStream_t st) {
     const int tn = (N + 32 * NWN - 1) / (32 * NWN);
-    hipLaunchKernelGGL((gemm_clip_kernel<NWM, NWN, EPI>), dim3(tn * B), dim3(64 * NWM * NWN), 0, st, A, lda, Bt, ldb, bias, C,
-                       ldc, Tp, N, K, tn, tn * B, rstd_io, act);
+    hipLaunchKernelGGL((gemm_clip_kernel<NWM, NWN, EPI, BK, DB>), dim3(tn * B), dim3(64 * NWM * NWN), 0, st, A, lda, Bt, ldb,
+                       bias, C, ldc, Tp, N, K, tn, tn * B, rstd_io, act);
 }
 
-// rows_per_clip = 32 * nwm (1..4).  epi: 0 plain, 1 forward IN+LeakyReLU, 2 backward of IN+LeakyReLU
+// rows_per_clip = 32 * nwm (1..4).  epi: 0 plain, 1 forward IN+LeakyReLU, 2 backward of IN+LeakyReLU.
+// cfg: 0 = BK 32 / one LDS buffer, 1 = BK 64 / one buffer, 2 = BK 32 / two buffers (same numerics)
+static int g_clip_cfg = 0;
+void set_gemm_clip_config(int cfg) { g_clip_cfg = cfg; }
 void launch_gemm_clip(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc, int B,
                       int nwm, int Tp, int N, int K, int epi, float* rstd_io, const float* act, hipStream_t st) {
-#define CL(M_, E_) clip_launch<M_, 4, E_>(A, lda, Bt, ldb, bias, C, ldc, B, Tp, N, K, rstd_io, act, st)
-#define CLM(E_)                                                             \
-    switch (nwm) { case 1: CL(1, E_); break; case 2: CL(2, E_); break; case 3: CL(3, E_); break; default: CL(4, E_); break; }
-    if (epi == EPI_FWD) { CLM(EPI_FWD) }
-    else if (epi == EPI_BWD) { CLM(EPI_BWD) }
-    else { CLM(EPI_PLAIN) }
+#define CL(M_, E_, K_, D_) clip_launch<M_, 4, E_, K_, D_>(A, lda, Bt, ldb, bias, C, ldc, B, Tp, N, K, rstd_io, act, st)
+#define CLM(E_, K_, D_)                                                                                            \
+    switch (nwm) { case 1: CL(1, E_, K_, D_); break; case 2: CL(2, E_, K_, D_); break; case 3: CL(3, E_, K_, D_); break; \
+                   default: CL(4, E_, K_, D_); break; }
+#define CLE(K_, D_)                                   \
+    if (epi == EPI_FWD) { CLM(EPI_FWD, K_, D_) }      \
+    else if (epi == EPI_BWD) { CLM(EPI_BWD, K_, D_) } \
+    else { CLM(EPI_PLAIN, K_, D_) }
+    if (g_clip_cfg == 1) { CLE(64, 1) }
+    else if (g_clip_cfg == 2) { CLE(32, 2) }
+    else { CLE(32, 1) }
+#undef CLE
 #undef CLM
 #undef CL
 }
@@ -773,8 +810,8 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_kernel(float* __restrict__ d
 __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ a3, const int* __restrict__ frame_off, const int* __restrict__ pool_off,
                                                     const float* __restrict__ target, float* __restrict__ pred,
                                                     float* __restrict__ loss_out, float* __restrict__ best_loss,
-                                                    int* __restrict__ improved, float* __restrict__ dA3, int loss_kind,
-                                                    int nbits) {
+                                                    int* __restrict__ improved, float* __restrict__ dA3, int* __restrict__ step,
+                                                    int loss_kind, int nbits) {
     __shared__ float part[4][64], mean[64], dm[64];
     const int b = blockIdx.x, c = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int r0 = pool_off[b], Tp = (frame_off[b + 1] - frame_off[b]) / 2;   // rows are 32-aligned per clip
@@ -819,6 +856,7 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ a3,
             const int imp = L < bl;
             improved[b] = imp;
             if (imp) best_loss[b] = L;
+            if (step && b == 0) *step += 1;
         }
         if (dA3 && c < nbits) {
             const float dpre = dp * (1.f - p * p);             // tanh'
@@ -833,7 +871,143 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ a3,
     }
 }
 
-__global__ void advance_step_kernel(int* step) { if (threadIdx.x == 0 && blockIdx.x == 0) *step += 1; }
+// ---------------------------------------------------------------------------------
+// Fused tail of the detector for clips of up to 128 pooled frames: sum of the last conv's
+// split-K partials + bias -> InstanceNorm -> LeakyReLU -> BRH read-out -> loss / best-loss
+// bookkeeping -> gradient back through the read-out, LeakyReLU and InstanceNorm.
+// One 256-thread workgroup per clip (64 channel slots x 4 row groups, activation in registers).
+// Writes pred, loss, improved, best_loss and dZ = dL/d(conv output) [rows][C]; advances the
+// optimiser step counter (block 0) when step != nullptr.
+// ---------------------------------------------------------------------------------
+template <int NSPLIT>
+__global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ zpart, size_t slab,
+                                                    const float* __restrict__ bias, const int* __restrict__ frame_off,
+                                                    const int* __restrict__ pool_off, const float* __restrict__ target,
+                                                    float* __restrict__ pred, float* __restrict__ loss_out,
+                                                    float* __restrict__ best_loss, int* __restrict__ improved,
+                                                    float* __restrict__ dZ, int* __restrict__ step, int loss_kind, int nbits) {
+    constexpr int R = 32;
+    __shared__ float red[4][64], red2[4][64], mean_s[64], dm[64];
+    const int b = blockIdx.x, c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int r0 = pool_off[b], Tp = (frame_off[b + 1] - frame_off[b]) / 2;
+    const int C = 2 * nbits;
+    const bool ok = c < C;
+    const float invT = 1.0f / (float)Tp;
+    float z[R];
+    const float bv = (ok && bias) ? bias[c] : 0.f;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int t = g + 4 * i;
+        z[i] = 0.f;
+        if (ok && t < Tp) {
+            float part[NSPLIT];
+#pragma unroll
+            for (int k = 0; k < NSPLIT; ++k) part[k] = zpart[k * slab + (size_t)(r0 + t) * C + c];
+            float acc = bv;
+#pragma unroll
+            for (int k = 0; k < NSPLIT; ++k) acc += part[k];
+            z[i] = acc;
+            s += acc;
+        }
+    }
+    red[g][c] = s;
+    __syncthreads();
+    const float mu = (red[0][c] + red[1][c] + red[2][c] + red[3][c]) * invT;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+        if (g + 4 * i < Tp) { const float d = z[i] - mu; q += d * d; }
+    red2[g][c] = q;
+    __syncthreads();
+    const float rs = 1.0f / sqrtf((red2[0][c] + red2[1][c] + red2[2][c] + red2[3][c]) * invT + 1e-5f);
+    // u = normalised pre-activation (kept in z), read-out mean of LeakyReLU(u)
+    float am = 0.f;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const float u = (z[i] - mu) * rs;
+        z[i] = u;
+        if (g + 4 * i < Tp) am += (u > 0.f ? u : 0.2f * u);
+    }
+    __syncthreads();
+    red[g][c] = am;
+    __syncthreads();
+    if (g == 0) mean_s[c] = ok ? (red[0][c] + red[1][c] + red[2][c] + red[3][c]) * invT : 0.f;
+    __syncthreads();
+    float lterm = 0.f, dp = 0.f, p = 0.f;
+    if (g == 0 && c < nbits) {
+        p = tanhf(mean_s[2 * c] - mean_s[2 * c + 1]);
+        pred[b * nbits + c] = p;
+        if (target) {
+            const float tg = target[b * nbits + c];
+            const float inv = 1.0f / (float)nbits;
+            if (loss_kind == 0) {
+                lterm = ((p - tg) * (p - tg) - 0.1f * fabsf(p)) * inv;
+                dp = (2.f * (p - tg) - 0.1f * ((p > 0.f) ? 1.f : (p < 0.f ? -1.f : 0.f))) * inv;
+            } else if (loss_kind == 1) {
+                lterm = (p - tg) * (p - tg) * inv;
+                dp = 2.f * (p - tg) * inv;
+            } else if (loss_kind == 2) {
+                float h = 1.f - p * tg;
+                lterm = (h > 0.f ? h : 0.f) * inv;
+                dp = (h > 0.f ? -tg : 0.f) * inv;
+            } else {
+                float h = -p * tg;
+                lterm = (h > 0.f ? h : 0.f) * inv;
+                dp = (h > 0.f ? -tg : 0.f) * inv;
+            }
+        }
+    }
+    if (!target) return;
+    if (g == 0) {
+        const float L = wave_sum(lterm);
+        if (c == 0) {
+            loss_out[b] = L;
+            const float bl = best_loss[b];
+            const int imp = L < bl;
+            improved[b] = imp;
+            if (imp) best_loss[b] = L;
+            if (step && b == 0) *step += 1;
+        }
+        if (c < nbits) {
+            const float dpre = dp * (1.f - p * p);             // tanh'
+            dm[2 * c] = dpre; dm[2 * c + 1] = -dpre;
+        }
+    }
+    if (!dZ) return;
+    __syncthreads();
+    // dA[t][c] = dm[c]/Tp ; dU = dA * lrelu'(u) ; InstanceNorm backward
+    const float ga = ok ? dm[c] * invT : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+        if (g + 4 * i < Tp) { const float du = ga * (z[i] > 0.f ? 1.f : 0.2f); s1 += du; s2 += du * z[i]; }
+    red[g][c] = s1; red2[g][c] = s2;
+    __syncthreads();
+    const float m1 = (red[0][c] + red[1][c] + red[2][c] + red[3][c]) * invT;
+    const float m2 = (red2[0][c] + red2[1][c] + red2[2][c] + red2[3][c]) * invT;
+    const int Tpad = (Tp + 31) & ~31;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int t = g + 4 * i;
+        if (ok && t < Tpad) {
+            const float du = ga * (z[i] > 0.f ? 1.f : 0.2f);
+            dZ[(size_t)(r0 + t) * C + c] = (t < Tp) ? rs * (du - m1 - z[i] * m2) : 0.f;
+        }
+    }
+}
+
+void launch_tail(const float* zpart, int nsplit, size_t slab, const float* bias, const int* frame_off, const int* pool_off,
+                 const float* target, float* pred, float* loss, float* best_loss, int* improved, float* dZ, int* step,
+                 int loss_kind, int nbits, int B, hipStream_t st) {
+    if (nsplit == 4)
+        hipLaunchKernelGGL(tail_kernel<4>, dim3(B), dim3(256), 0, st, zpart, slab, bias, frame_off, pool_off, target, pred,
+                           loss, best_loss, improved, dZ, step, loss_kind, nbits);
+    else
+        hipLaunchKernelGGL(tail_kernel<1>, dim3(B), dim3(256), 0, st, zpart, slab, bias, frame_off, pool_off, target, pred,
+                           loss, best_loss, improved, dZ, step, loss_kind, nbits);
+}
+
 
 void launch_mel_norm_fwd(const float* xm, const int* frame_off, const int* pool_off, float* x0, float* stats,
                          float* gstat, float* part, int pstride, int B, int max_frames, hipStream_t st) {
@@ -866,9 +1040,7 @@ void launch_head(const float* a3, const int* frame_off, const int* pool_off, con
                  float* best_loss, int* improved, float* dA3, int* step, int loss_kind, int nbits, int B,
                  hipStream_t st) {
     hipLaunchKernelGGL(head_kernel, dim3(B), dim3(256), 0, st, a3, frame_off, pool_off, target, pred, loss, best_loss, improved, dA3,
-                       loss_kind, nbits);
-    (void)step;
+                       step, loss_kind, nbits);
 }
-void launch_advance_step(int* step, hipStream_t st) { hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(64), 0, st, step); }
 
 }  // namespace aware

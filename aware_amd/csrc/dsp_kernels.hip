@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kThreads) void analysis_kernel(AnalysisArgs a) {
     float4 sc = make_float4(0.f, 0.f, 1.f, 0.f);
     int improved = 0;
     if (MODE == AN_ADJ && a.do_step) {
-        sc = a.sched[*a.step];
+        sc = a.sched[*a.step - 1];      // the read-out kernel of this iteration already advanced the counter
         improved = a.improved[b];
     }
 

@@ -77,6 +77,7 @@ int gemm_autotune(const float* A, int lda, const float* Bt, int ldb, float* C, i
 // clip-aligned GEMM with fused InstanceNorm+LeakyReLU epilogues (uniform batches, <= 128 pooled rows per clip)
 void launch_gemm_clip(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc, int B,
                       int nwm, int Tp, int N, int K, int epi, float* rstd_io, const float* act, hipStream_t st);
+void set_gemm_clip_config(int cfg);
 // mel block: InstanceNorm over time, per-clip GlobalStandardize, AvgPool(2,2)
 void launch_mel_norm_fwd(const float* xm, const int* frame_off, const int* pool_off, float* x0, float* stats,
                          float* gstat, float* part, int pstride, int B, int max_frames, hipStream_t st);
@@ -92,7 +93,11 @@ void launch_in_lrelu_bwd(float* dA, const float* A, const int* frame_off, const 
 void launch_head(const float* a3, const int* frame_off, const int* pool_off, const float* target, float* pred, float* loss,
                  float* best_loss, int* improved, float* dA3, int* step, int loss_kind, int nbits, int B,
                  hipStream_t st);
-void launch_advance_step(int* step, hipStream_t st);
+void launch_gemm_nt_splitk(const float* A, int lda, const float* Bt, int ldb, float* Cpart, int ldc, int M, int N, int K,
+                           int ksplit, hipStream_t st);
+void launch_tail(const float* zpart, int nsplit, size_t slab, const float* bias, const int* frame_off, const int* pool_off,
+                 const float* target, float* pred, float* loss, float* best_loss, int* improved, float* dZ, int* step,
+                 int loss_kind, int nbits, int B, hipStream_t st);
 
 // ---- attack_kernels.hip -----------------------------------------------------------------
 void launch_pcm_quantize(const float* in, float* out, const int* off, const int* len, const unsigned long long* pmax,

@@ -47,6 +47,9 @@ typedef struct aware_embed aware_embed;
 
 int aware_version(void);
 const char* aware_last_hip_error(void);
+/* development knob, not part of the drop-in surface: key 1 = K-tile / LDS buffering of the
+ * clip-aligned GEMM (0: BK 32 x1, 1: BK 64 x1, 2: BK 32 x2); every setting gives identical results */
+int aware_tune(int key, int value);
 
 /* ---- plan: FFT twiddles, window, band ------------------------------------------------
  * Replaces the constructor state of STFT / ISTFT (src/AWARE/utils/audio/stft.py:14-25,

@@ -10,6 +10,8 @@ iters = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 graph = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 n = 48000
 plan = rt.Plan()
+if len(sys.argv) > 4:
+    plan.lib.aware_tune(1, int(sys.argv[4]))
 ws, bs = O.detector_weights()
 det = rt.DetectorWeights(plan, O.mel_filter_bank(), [w.numpy() for w in ws], [b.numpy() for b in bs])
 batch = rt.Batch([n] * B)
