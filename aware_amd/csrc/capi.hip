@@ -46,7 +46,7 @@ static inline void prof_mark(int kind) {
 #define PROF(kind) prof_mark(kind)
 // kernel kinds reported by aware_embed_profile
 enum { K_SYNTH = 0, K_ANALYSIS = 1, K_GEMM = 2, K_MELNORM = 3, K_INLRELU = 4, K_HEAD = 5, K_SYNTH_ADJ = 6,
-       K_ANALYSIS_ADJ = 7, K_MISC = 8 };
+       K_ANALYSIS_ADJ = 7, K_MISC = 8, K_GEMM_CLIP_FWD = 9, K_GEMM_CLIP_BWD = 10 };
 
 static int absmax_into_scratch(const float* in, const int* off, const int* len, int B, int max_len, void* scratch,
                                unsigned long long** pmax_out, int** pcount_out, int* ps_out, hipStream_t st);
@@ -427,7 +427,7 @@ static int det_forward(const aware_detector* d, const aware_batch* b, const floa
             // conv + InstanceNorm + LeakyReLU in one kernel (clip-aligned tiles)
             launch_gemm_clip(x, ci, d->w[l], ci, d->bias[l], o.act[l], co, b->B, nwm, b->uniform_tp, co, ci, 1, o.rstd[l],
                              nullptr, st);
-            LAUNCHCHK(); PROF(K_GEMM);
+            LAUNCHCHK(); PROF(K_GEMM_CLIP_FWD);
         } else {
             launch_gemm_nt(x, ci, d->w[l], ci, d->bias[l], o.act[l], co, b->NP, co, ci, st);
             LAUNCHCHK(); PROF(K_GEMM);
@@ -700,11 +700,12 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
             launch_gemm_clip(dA, co, d->wT[l], co, nullptr, dB, ci, b->B, nwm, b->uniform_tp, ci, co, 2, e->db.rstd[l - 1],
                              e->db.act[l - 1], st);
             dz_ready = true;
+            LAUNCHCHK(); PROF(K_GEMM_CLIP_BWD);
         } else {
             launch_gemm_nt(dA, co, d->wT[l], co, nullptr, dB, ci, b->NP, ci, co, st);
             dz_ready = false;
+            LAUNCHCHK(); PROF(K_GEMM);
         }
-        LAUNCHCHK(); PROF(K_GEMM);
         float* t = dA; dA = dB; dB = t;
     }
     launch_mel_norm_bwd(dA, e->db.xm, b->d_frame_off, b->d_pool_off, e->db.mstats, e->db.gstat, e->db.mpart,

@@ -381,7 +381,8 @@ def gaussian_noise(x: Ragged, snr_db: float, seeds: Sequence[int]) -> Ragged:
     return out
 
 
-KERNEL_KINDS = ["synth", "analysis", "gemm", "mel_norm", "in_lrelu", "head", "synth_adjoint", "analysis_adjoint_nadam", "misc"]
+KERNEL_KINDS = ["synth", "analysis", "gemm_nt", "mel_norm", "in_lrelu", "readout_tail", "synth_adjoint",
+                "analysis_adjoint_nadam", "misc", "gemm_clip_fwd", "gemm_clip_bwd"]
 
 
 def embed_profile(sess: EmbedSession, n_iters: int = 3):

@@ -138,8 +138,9 @@ int aware_embed_iterate(aware_embed* e, int n_iters, void* stream);
 int aware_embed_gradient(aware_embed* e, float* grad, void* stream);
 /* Timing aid for the roofline report: runs n_iters loop bodies eagerly with a HIP event recorded on
  * `stream` after every kernel launch; writes the elapsed milliseconds between consecutive events and
- * a kernel kind per launch (0 synth, 1 analysis, 2 gemm, 3 mel-norm, 4 in+lrelu, 5 head, 6 synth
- * adjoint, 7 analysis adjoint + NAdam, 8 misc).  Synchronises the stream.  Returns the number of
+ * a kernel kind per launch (0 synth, 1 analysis, 2 generic gemm, 3 mel-norm, 4 in+lrelu, 5 read-out/tail,
+ * 6 synth adjoint, 7 analysis adjoint + NAdam, 8 misc, 9 clip-aligned gemm with fused forward
+ * epilogue, 10 the same with fused backward epilogue).  Synchronises the stream.  Returns the number of
  * entries written or a negative error.  (These iterations DO step the optimiser.) */
 int aware_embed_profile(aware_embed* e, int n_iters, int max_entries, float* ms_out, int* kind_out, void* stream);
 /* final synthesis from the best coefficients (:173-194) and the service-level rescale
