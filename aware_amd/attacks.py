@@ -216,6 +216,28 @@ class GaussianNoise(Attack):
         return rt.gaussian_noise(x, self.snr_db, seeds)
 
 
+@register
+class MP3Surrogate(Attack):
+    """EXTENSION (not in the reference; BASELINE.json north_star): MP3-like quantisation surrogate
+    -- STFT -> per-frame log-magnitude quantisation (`step_db` grid, bins more than `-floor_db` below
+    the frame maximum dropped) -> iSTFT.  It is NOT a codec and does not replace the reference's
+    ffmpeg-based MP3Compression (out of scope: external binary).  Specified by
+    oracle/aware_oracle.py::mp3_surrogate_attack -- parity unpinned.  Output length 256*(T-1)."""
+
+    def __init__(self, step_db=1.5, floor_db=-60.0):
+        self.step_db, self.floor_db = float(step_db), float(floor_db)
+        self.name = f"mp3_surrogate_{step_db}dB"
+
+    def apply_batch(self, x, sr):
+        from .utils.audio import default_plan
+        plan = default_plan()
+        batch = x.batch()
+        spec = rt.stft(plan, batch, x.data, normalize=False)
+        rt.spectral_quantize(spec, self.step_db, self.floor_db)
+        y = rt.istft(plan, batch, spec, normalize=False)
+        return rt.Ragged(y, batch.out_lengths)
+
+
 def reference_attack_list():
     """The subset of the harness's 22-entry list (scripts/test.py:15-18) that runs here."""
     return [PCMBitDepthConversion(8), PCMBitDepthConversion(12), PCMBitDepthConversion(16), PCMBitDepthConversion(24),

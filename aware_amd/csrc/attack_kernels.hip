@@ -234,3 +234,50 @@ void launch_segment_copy(const float* in, const int* in_off, float* out, const i
 }
 
 }  // namespace aware
+
+// ---------------------------------------------------------------------------------
+// EXTENSION (not in the reference; BASELINE.json north_star "MP3-like quantisation
+// surrogate"): per-frame log-magnitude quantisation of a full one-sided spectrum.
+// Specification: oracle/aware_oracle.py::mp3_surrogate_attack.  One wave per frame:
+//   fmax = max_k |X_k| ; db = 20 log10(|X| / fmax) ; q = round(db / step) * step ;
+//   |X| <- fmax * 10^(q/20), zero where db < floor ; the phase is kept.
+// spec: [frames][520] complex64 (bins 0..512), in place.
+// ---------------------------------------------------------------------------------
+namespace aware {
+__global__ __launch_bounds__(256) void spectral_quantize_kernel(cf* __restrict__ spec, int nframes, float step_db,
+                                                                 float floor_db) {
+    const int frame = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (frame >= nframes) return;
+    cf* X = spec + (size_t)frame * 520;
+    float mg[9];
+    float mx = 0.f;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        const int k = lane + 64 * r;
+        mg[r] = 0.f;
+        if (k <= 512) { cf x = X[k]; mg[r] = sqrtf(x.x * x.x + x.y * x.y); }
+        mx = fmaxf(mx, mg[r]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    mx = fmaxf(mx, 1e-12f);
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        const int k = lane + 64 * r;
+        if (k > 512) continue;
+        const float m = fmaxf(mg[r], 1e-12f);
+        const float db = 20.0f * log10f(m / mx);
+        const float q = rintf(db / step_db) * step_db;          // torch.round: half to even
+        float mq = mx * powf(10.0f, q / 20.0f);
+        if (db < floor_db) mq = 0.f;
+        const float sc = (mg[r] > 0.f) ? mq / mg[r] : 0.f;      // keep the phase
+        cf x = X[k];
+        X[k] = mk(x.x * sc, x.y * sc);
+    }
+}
+void launch_spectral_quantize(void* spec, int nframes, float step_db, float floor_db, hipStream_t st) {
+    hipLaunchKernelGGL(spectral_quantize_kernel, dim3((nframes + 3) / 4), dim3(256), 0, st, (cf*)spec, nframes, step_db,
+                       floor_db);
+}
+}  // namespace aware

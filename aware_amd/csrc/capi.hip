@@ -900,6 +900,13 @@ extern "C" int aware_gaussian_noise(const float* in, float* out, const int* off,
     return AWARE_OK;
 }
 
+extern "C" int aware_spectral_quantize(void* spec, int n_frames, float step_db, float floor_db, void* stream) {
+    if (!spec || n_frames < 1 || !(step_db > 0.f)) return AWARE_E_BADARG;
+    launch_spectral_quantize(spec, n_frames, step_db, floor_db, (hipStream_t)stream);
+    LAUNCHCHK();
+    return AWARE_OK;
+}
+
 extern "C" int aware_gemm_nt_variant(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C,
                                      int ldc, int M, int N, int K, int variant, void* stream) {
     if (!A || !Bt || !C || M < 1 || N < 1 || K < 4 || (K & 3) || (lda & 3) || (ldb & 3) || variant < 0 || variant > 16)

@@ -50,9 +50,13 @@ class WatermarkPipeline:
         vals = self.detector.detect_device(data, self._sessions[key], self.sample_rate)
         return (vals > self.detector.threshold).to(torch.int32), vals
 
-    def run(self, audio: "rt.Ragged", bits: torch.Tensor, input_rate: int | None = None) -> PipelineResult:
+    def run(self, audio: "rt.Ragged", bits: torch.Tensor, input_rate: int | None = None, chains=None,
+            chain_of_clip=None) -> PipelineResult:
         """audio: ragged device clips at `input_rate` (default: the pipeline's 16 kHz);
-        bits: device int tensor [B, n_bits] of 0/1."""
+        bits: device int tensor [B, n_bits] of 0/1.
+        chains / chain_of_clip (BASELINE config 5): `chains` is a list of attack lists and
+        `chain_of_clip[b]` the index of the chain applied to clip b; clips are grouped by chain so that
+        no workgroup ever branches on the attack kind."""
         input_rate = input_rate or self.sample_rate
         seconds = float(sum(audio.lengths)) / float(input_rate)
         x = audio
@@ -69,6 +73,25 @@ class WatermarkPipeline:
         clean_bits, clean_vals = self._detect_bits(wm)
         clean_err = (clean_bits != bits).sum()
         per = {}
+        if chains is not None:
+            det_bits = torch.empty_like(clean_bits)
+            vals = torch.empty_like(clean_vals)
+            for cid, chain in enumerate(chains):
+                members = [i for i, c in enumerate(chain_of_clip) if c == cid]
+                if not members:
+                    continue
+                y = wm.select(members)
+                for a in chain:
+                    if y.data.dtype != torch.float32:
+                        y = rt.Ragged(y.data.float(), y.lengths)
+                    y = a.apply_batch(y, self.sample_rate)
+                gb, gv = self._detect_bits(y)
+                idx = torch.tensor(members, device=bits.device)
+                det_bits[idx] = gb
+                vals[idx] = gv
+                per["+".join(a.name for a in chain) or "none"] = (gb != bits[idx]).sum()
+            err = (det_bits != bits).sum()
+            return PipelineResult(det_bits, vals, err, clean_err, wm, per, seconds)
         if not self.attacks:
             return PipelineResult(clean_bits, clean_vals, clean_err, clean_err, wm, per, seconds)
         if self.attack_mode == "chain":

@@ -297,6 +297,11 @@ class Ragged:
         data = torch.cat([torch.as_tensor(np.asarray(c), dtype=dtype) for c in clips]).to(_dev())
         return cls(data, lengths)
 
+    def select(self, indices):
+        """sub-batch of the given clips (device-side gather of their spans)"""
+        parts = [self.data[self.offsets[i]: self.offsets[i] + self.lengths[i]] for i in indices]
+        return Ragged(torch.cat(parts) if len(parts) > 1 else parts[0].clone(), [self.lengths[i] for i in indices])
+
     def like(self, dtype=None):
         return Ragged(torch.empty_like(self.data, dtype=dtype or self.data.dtype), self.lengths)
 
@@ -395,3 +400,11 @@ def embed_profile(sess: EmbedSession, n_iters: int = 3):
     if n < 0:
         check(n, "aware_embed_profile")
     return [(KERNEL_KINDS[kind[i]], float(ms[i])) for i in range(n)]
+
+
+def spectral_quantize(spec: torch.Tensor, step_db: float, floor_db: float) -> torch.Tensor:
+    """in place on a [frames, 520] complex64 spectrum (EXTENSION: MP3-like surrogate)"""
+    lib = load_library()
+    check(lib.aware_spectral_quantize(_ptr(spec), spec.shape[0], float(step_db), float(floor_db), _stream()),
+          "aware_spectral_quantize")
+    return spec

@@ -180,6 +180,12 @@ int aware_segment_cut(const float* in, const int* in_off, float* out, const int*
 int aware_gaussian_noise(const float* in, float* out, const int* off, const int* len, int B, int max_len,
                          const uint32_t* seeds, float snr_db, void* scratch, void* stream);
 
+/* EXTENSION (not in the reference): MP3-like quantisation surrogate on a full one-sided spectrum
+ * [n_frames][AWARE_FULL_STRIDE] complex64, in place: per frame the magnitudes are quantised on a
+ * step_db grid relative to the frame maximum and zeroed below floor_db; the phase is kept.
+ * Used as  aware_stft -> aware_spectral_quantize -> aware_istft. */
+int aware_spectral_quantize(void* spec, int n_frames, float step_db, float floor_db, void* stream);
+
 /* ---- bare GEMM (tests / roofline): C[M][N] = A[M][K] * Bt[N][K]^T + bias ------------------------------ */
 int aware_gemm_nt(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc,
                   int M, int N, int K, void* stream);

@@ -105,3 +105,16 @@ def test_detector_on_attacked_audio_matches_reference(A, gold):
     vals = det.detect_batch([gold[k + "/out"] for k in keys], 16000).cpu().numpy()
     for k, v in zip(keys, vals):
         np.testing.assert_allclose(v, gold[k + "/det_raw"], atol=1e-4)
+
+
+def test_mp3_surrogate_extension(A):
+    """EXTENSION -- parity unpinned: checked against its specification in the oracle.  A magnitude
+    sitting exactly on a quantiser boundary may round differently (log10 differs in the last ulp
+    between CPU and GPU), so the comparison is in the L2 sense."""
+    from oracle import aware_oracle as O
+    a, _ = make_clip(8, 16000)
+    out = A.MP3Surrogate(1.5, -60.0).apply(a, 16000)
+    ref = O.mp3_surrogate_attack(a, 1.5, -60.0)
+    assert out.shape == ref.shape == (15872,)
+    assert np.linalg.norm(out - ref) / np.linalg.norm(ref) < 2e-3
+    assert 0.5 < np.linalg.norm(out) / np.linalg.norm(a[:15872]) < 1.5

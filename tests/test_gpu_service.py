@@ -147,3 +147,85 @@ def test_pipeline_attack_chain_and_each(models):
     assert int(each.per_attack_errors["pcm_16"]) == 0
     # robustness is not asserted bit-exactly under attacks; BER must stay far below chance (50 %)
     assert int(chain.bit_errors) <= 0.25 * bits.numel()
+
+
+def test_config5_ragged_clips_with_per_clip_chains(models):
+    """BASELINE config 5 in miniature: mixed-length clips, a randomly drawn attack chain per clip,
+    clips grouped by chain id."""
+    import random
+    from aware_amd import runtime as rt
+    from aware_amd.pipeline import WatermarkPipeline
+    from aware_amd.attacks import PCMBitDepthConversion, LowPassFilter, GaussianNoise, Resample, SampleSupression
+    emb, det = models
+    rng = np.random.default_rng(5)
+    lens = [16000, 24000, 32000, 20000, 16000, 40000]
+    pairs = [make_clip(60 + i, n) for i, n in enumerate(lens)]
+    audio = rt.Ragged.from_list([p[0] for p in pairs])
+    bits = torch.tensor(np.stack([p[1] for p in pairs]), dtype=torch.int32, device="cuda")
+    chains = [[], [PCMBitDepthConversion(16)], [LowPassFilter(), GaussianNoise(30.0)], [Resample(), PCMBitDepthConversion(8)]]
+    random.seed(3)
+    chain_of_clip = [random.randrange(len(chains)) for _ in lens]
+    res = WatermarkPipeline(emb, det, [], 16000).run(audio, bits, chains=chains, chain_of_clip=chain_of_clip)
+    assert int(res.clean_bit_errors) == 0
+    assert res.bits.shape == bits.shape
+    # un-attacked and 16-bit PCM clips decode exactly; the rest stay far below chance
+    for i, c in enumerate(chain_of_clip):
+        wrong = int((res.bits[i] != bits[i]).sum())
+        assert wrong == 0 if c in (0, 1) else wrong <= 6, (i, c, wrong)
+
+
+def test_losses_and_windows_first_gradient(models):
+    """Other registered losses (mse, hinge, sign) and the hamming window: first-iteration loss and
+    gradient against torch autograd on the oracle."""
+    from oracle import aware_oracle as O
+    from aware_amd import runtime as rt
+    from aware_amd.utils.audio import get_plan
+    emb, det = models
+    audio, bits = make_clip(21, 16000)
+    wm = O.bits_to_bipolar(bits).astype(np.float32)
+    plan = get_plan()
+    dw = emb.detection_net.device_weights(plan)
+    batch = rt.Batch([16000])
+    for loss in ("mse", "hinge", "sign"):
+        sess = rt.EmbedSession(plan, dw, batch, loss=loss, use_graph=False)
+        sess.begin(batch.pack([audio]), torch.from_numpy(wm[None]).cuda())
+        g = sess.gradient().cpu()[:, :225].T
+        oe = O.Embedder(loss=loss)
+        a = torch.from_numpy(audio)[None]
+        mag0, phase = oe.analyse(a)
+        c0 = mag0[:, oe.band].clone().requires_grad_(True)
+        l, _ = oe.forward_loss(c0, mag0, phase, torch.from_numpy(wm)[None])
+        l.sum().backward()
+        assert abs(float(sess.loss.cpu()[0]) - float(l)) < 2e-5
+        ref = c0.grad[0]
+        if float(ref.norm()) > 0:
+            assert float((g - ref).norm() / ref.norm()) < 3e-3, loss
+        else:
+            assert float(g.abs().max()) == 0.0
+
+
+def test_edge_cases(models):
+    from aware_amd import runtime as rt
+    from aware_amd.service import embed_watermark, detect_watermark
+    emb, det = models
+    with pytest.raises(ValueError):
+        rt.Batch([512])                                     # torch.stft's reflect padding needs n > 512
+    # shortest legal clip (3 frames) and a 10 s clip (T = 626) in one ragged batch
+    a_short, b_short = make_clip(70, 513)
+    a_long, b_long = make_clip(71, 160000)
+    vals = det.detect_batch([a_short, a_long], 16000)
+    assert vals.shape == (2, 20) and bool(torch.isfinite(vals).all())
+    from oracle import aware_oracle as O
+    ref = O.Embedder().detect_raw(a_long[None])[0].numpy()
+    np.testing.assert_allclose(vals[1].cpu().numpy(), ref, atol=5e-5)
+    # all-zero audio is finite end to end (the reference would stop it at the VAD gate)
+    z = det.detect(np.zeros(16000, dtype=np.float32), 16000)
+    assert np.isfinite(z).all()
+    # 10 s clip through the generic (unfused) embed path, few iterations
+    emb2_iters = emb.num_iterations
+    try:
+        emb.num_iterations = 3
+        out = emb.embed(a_long, 16000, O.bits_to_bipolar(b_long))
+        assert out.shape == (160000,) and np.isfinite(out).all() and abs(np.abs(out).max() - 1.0) < 1e-6
+    finally:
+        emb.num_iterations = emb2_iters
