@@ -77,52 +77,94 @@ __global__ __launch_bounds__(256) void upfirdn_kernel(const float* __restrict__ 
 // state.  mode 1: filtfilt (odd extension by 3*ncoef samples, steady-state initial
 // conditions zi*x0, forward then backward); needs scratch[B][maxlen + 6*ncoef] doubles.
 constexpr int kMaxCoef = 12;
+// NC = number of coefficients (filter order + 1), compile-time so that the state lives in
+// registers; samples are fetched 16 at a time so that the load latency is paid once per 16
+// steps of the recurrence instead of once per step.
+template <int NC>
 __global__ __launch_bounds__(64) void iir_kernel(const float* __restrict__ in, const int* __restrict__ off,
                                                   const int* __restrict__ len, void* __restrict__ outv, int out_f64,
                                                   const double* __restrict__ bc, const double* __restrict__ ac,
-                                                  const double* __restrict__ zic, int ncoef, int mode,
+                                                  const double* __restrict__ zic, int mode,
                                                   double* __restrict__ scratch, int sstride, int B) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    double bb[kMaxCoef], aa[kMaxCoef], z[kMaxCoef];
-    for (int k = 0; k < kMaxCoef; ++k) {
-        bb[k] = k < ncoef ? bc[(size_t)b * ncoef + k] : 0.0;
-        aa[k] = k < ncoef ? ac[(size_t)b * ncoef + k] : 0.0;
-        z[k] = 0.0;
-    }
+    constexpr int NS = NC - 1;
+    double bb[NC], aa[NC], z[NS];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) { bb[k] = bc[(size_t)b * NC + k]; aa[k] = ac[(size_t)b * NC + k]; }
+#pragma unroll
+    for (int k = 0; k < NS; ++k) z[k] = 0.0;
     const int n = len[b];
     const float* x = in + off[b];
     double* od = reinterpret_cast<double*>(outv) + off[b];
     float* of = reinterpret_cast<float*>(outv) + off[b];
-    const int ns = ncoef - 1;
     auto step = [&](double xi) {
-        double yi = bb[0] * xi + z[0];
-        for (int k = 0; k < ns - 1; ++k) z[k] = z[k + 1] + bb[k + 1] * xi - aa[k + 1] * yi;
-        z[ns - 1] = bb[ns] * xi - aa[ns] * yi;
+        const double yi = bb[0] * xi + z[0];
+#pragma unroll
+        for (int k = 0; k < NS - 1; ++k) z[k] = z[k + 1] + bb[k + 1] * xi - aa[k + 1] * yi;
+        z[NS - 1] = bb[NS] * xi - aa[NS] * yi;
         return yi;
     };
+    constexpr int CH = 16;
     if (mode == 0) {
-        for (int i = 0; i < n; ++i) {
-            double yi = step((double)x[i]);
+        int i = 0;
+        for (; i + CH <= n; i += CH) {
+            float xb[CH];
+            double yb[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) xb[j] = x[i + j];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) yb[j] = step((double)xb[j]);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) { if (out_f64) od[i + j] = yb[j]; else of[i + j] = (float)yb[j]; }
+        }
+        for (; i < n; ++i) {
+            const double yi = step((double)x[i]);
             if (out_f64) od[i] = yi; else of[i] = (float)yi;
         }
         return;
     }
-    const int edge = 3 * ncoef;
+    const int edge = 3 * NC;
     double* s = scratch + (size_t)b * sstride;
     const int ne = n + 2 * edge;
-    // odd extension
+    // odd extension (scipy filtfilt padtype='odd', padlen = 3*max(len(a), len(b)))
     const double x0 = (double)x[0], xl = (double)x[n - 1];
     for (int i = 0; i < edge; ++i) s[i] = 2.0 * x0 - (double)x[edge - i];
     for (int i = 0; i < n; ++i) s[edge + i] = (double)x[i];
     for (int i = 0; i < edge; ++i) s[edge + n + i] = 2.0 * xl - (double)x[n - 2 - i];
     // forward
-    for (int k = 0; k < ns; ++k) z[k] = zic[(size_t)b * ns + k] * s[0];
-    for (int i = 0; i < ne; ++i) s[i] = step(s[i]);
+#pragma unroll
+    for (int k = 0; k < NS; ++k) z[k] = zic[(size_t)b * NS + k] * s[0];
+    {
+        int i = 0;
+        for (; i + CH <= ne; i += CH) {
+            double xb[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) xb[j] = s[i + j];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) xb[j] = step(xb[j]);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) s[i + j] = xb[j];
+        }
+        for (; i < ne; ++i) s[i] = step(s[i]);
+    }
     // backward
     const double y0 = s[ne - 1];
-    for (int k = 0; k < ns; ++k) z[k] = zic[(size_t)b * ns + k] * y0;
-    for (int i = ne - 1; i >= 0; --i) s[i] = step(s[i]);
+#pragma unroll
+    for (int k = 0; k < NS; ++k) z[k] = zic[(size_t)b * NS + k] * y0;
+    {
+        int i = ne - 1;
+        for (; i - CH + 1 >= 0; i -= CH) {
+            double xb[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) xb[j] = s[i - j];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) xb[j] = step(xb[j]);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) s[i - j] = xb[j];
+        }
+        for (; i >= 0; --i) s[i] = step(s[i]);
+    }
     for (int i = 0; i < n; ++i) {
         if (out_f64) od[i] = s[edge + i]; else of[i] = (float)s[edge + i];
     }
@@ -218,8 +260,15 @@ void launch_upfirdn(const float* in, const int* in_off, const int* in_len, float
 void launch_iir_full(const float* in, const int* off, const int* len, void* out, int out_f64, const double* b,
                      const double* a, const double* zi, int ncoef, int mode, double* scratch, int sstride, int B,
                      hipStream_t st) {
-    hipLaunchKernelGGL(iir_kernel, dim3((B + 63) / 64), dim3(64), 0, st, in, off, len, out, out_f64, b, a, zi, ncoef,
-                       mode, scratch, sstride, B);
+#define IIR(NC_)                                                                                                       \
+    hipLaunchKernelGGL(iir_kernel<NC_>, dim3((B + 63) / 64), dim3(64), 0, st, in, off, len, out, out_f64, b, a, zi, mode, \
+                       scratch, sstride, B)
+    switch (ncoef) {
+        case 2: IIR(2); break; case 3: IIR(3); break; case 4: IIR(4); break; case 5: IIR(5); break;
+        case 6: IIR(6); break; case 7: IIR(7); break; case 8: IIR(8); break; case 9: IIR(9); break;
+        case 10: IIR(10); break; case 11: IIR(11); break; default: IIR(12); break;
+    }
+#undef IIR
 }
 void launch_gaussian_noise_full(const float* in, float* out, const int* off, const int* len, const unsigned* seeds,
                                 double* power, float snr_db, int B, int max_len, hipStream_t st) {
