@@ -110,6 +110,8 @@ def load_library():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    if os.environ.get("AWARE_TUNE_CLIP"):          # development knob, see aware_tune() in the header
+        lib.aware_tune(1, int(os.environ["AWARE_TUNE_CLIP"]))
     _lib = lib
     return lib
 

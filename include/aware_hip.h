@@ -48,7 +48,8 @@ typedef struct aware_embed aware_embed;
 int aware_version(void);
 const char* aware_last_hip_error(void);
 /* development knob, not part of the drop-in surface: key 1 = K-tile / LDS buffering of the
- * clip-aligned GEMM (0: BK 32 x1, 1: BK 64 x1, 2: BK 32 x2); every setting gives identical results */
+ * clip-aligned GEMM (0: BK 32 x1 [default, fastest measured], 1: BK 64 x1, 2: BK 32 x2, 3: direct-to-LDS
+ * loads x2); every setting gives identical results */
 int aware_tune(int key, int value);
 
 /* ---- plan: FFT twiddles, window, band ------------------------------------------------
@@ -189,7 +190,7 @@ int aware_spectral_quantize(void* spec, int n_frames, float step_db, float floor
 /* ---- bare GEMM (tests / roofline): C[M][N] = A[M][K] * Bt[N][K]^T + bias ------------------------------ */
 int aware_gemm_nt(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc,
                   int M, int N, int K, void* stream);
-/* same with an explicit tile configuration: variant 0 = automatic, 1..12 = fixed (tuning aid; all
+/* same with an explicit tile configuration: variant 0 = automatic, 1..16 = fixed (tuning aid; all
  * configurations produce bit-identical results) */
 int aware_gemm_nt_variant(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc,
                           int M, int N, int K, int variant, void* stream);
