@@ -280,7 +280,7 @@ __device__ __forceinline__ void clip_epilogue(const f32x16& acc, float (*red1)[3
 }
 
 
-template <int NWM, int NWN, int EPI, int BK, int DB>
+template <int NWM, int NWN, int EPI, int BK, int DB, bool EXACT>
 __global__ __launch_bounds__(64 * NWM * NWN) void gemm_clip_kernel(const float* __restrict__ A, int lda,
                                                                     const float* __restrict__ Bt, int ldb,
                                                                     const float* __restrict__ bias, float* __restrict__ C,
@@ -315,12 +315,15 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_clip_kernel(const float* 
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
             int rl = lrow + RPP * i, k = k0 + lkq;
-            ra[i] = (rl < BM && k < K) ? *reinterpret_cast<const float4*>(A + (size_t)(bm + rl) * lda + k) : make_float4(0, 0, 0, 0);
+            // EXACT: K % BK == 0 and N % BN == 0, so only the static row-count guard remains
+            const bool ok = (BM % RPP == 0 || rl < BM) && (EXACT || k < K);
+            ra[i] = ok ? *reinterpret_cast<const float4*>(A + (size_t)(bm + rl) * lda + k) : make_float4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
             int rl = lrow + RPP * i, r = bn + rl, k = k0 + lkq;
-            rb[i] = (rl < BN && r < N && k < K) ? *reinterpret_cast<const float4*>(Bt + (size_t)r * ldb + k) : make_float4(0, 0, 0, 0);
+            const bool ok = (BN % RPP == 0 || rl < BN) && (EXACT || (r < N && k < K));
+            rb[i] = ok ? *reinterpret_cast<const float4*>(Bt + (size_t)r * ldb + k) : make_float4(0, 0, 0, 0);
         }
     };
     auto sstore = [&](int buf) {
@@ -481,8 +484,12 @@ template <int NWM, int NWN, int EPI, int BK, int DB>
 static void clip_launch(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc, int B,
                         int Tp, int N, int K, float* rstd_io, const float* act, hipStream_t st) {
     const int tn = (N + 32 * NWN - 1) / (32 * NWN);
-    hipLaunchKernelGGL((gemm_clip_kernel<NWM, NWN, EPI, BK, DB>), dim3(tn * B), dim3(64 * NWM * NWN), 0, st, A, lda, Bt, ldb,
-                       bias, C, ldc, Tp, N, K, tn, tn * B, rstd_io, act);
+    if (K % BK == 0 && N % (32 * NWN) == 0)
+        hipLaunchKernelGGL((gemm_clip_kernel<NWM, NWN, EPI, BK, DB, true>), dim3(tn * B), dim3(64 * NWM * NWN), 0, st, A, lda, Bt,
+                           ldb, bias, C, ldc, Tp, N, K, tn, tn * B, rstd_io, act);
+    else
+        hipLaunchKernelGGL((gemm_clip_kernel<NWM, NWN, EPI, BK, DB, false>), dim3(tn * B), dim3(64 * NWM * NWN), 0, st, A, lda, Bt,
+                           ldb, bias, C, ldc, Tp, N, K, tn, tn * B, rstd_io, act);
 }
 
 // rows_per_clip = 32 * nwm (1..4).  epi: 0 plain, 1 forward IN+LeakyReLU, 2 backward of IN+LeakyReLU.
