@@ -229,3 +229,32 @@ def test_edge_cases(models):
         assert out.shape == (160000,) and np.isfinite(out).all() and abs(np.abs(out).max() - 1.0) < 1e-6
     finally:
         emb.num_iterations = emb2_iters
+
+
+def test_full_size_config1_properties(models):
+    """BASELINE config 1 at full size (64 x 3 s clips from 44.1 kHz): size-independent properties --
+    every clip decodes exactly (BER 0), the best loss improved on the first iteration's for every
+    clip, the watermark stays inside the +-6 dB box, outputs are unit-peak times the input maximum,
+    and a second run is bit-identical (no atomics anywhere on the path)."""
+    from aware_amd.pipeline import WatermarkPipeline, synthetic_clips
+    emb, det = models
+    audio, bits = synthetic_clips(64, 3.0, 44100, first_seed=1000)
+    pipe = WatermarkPipeline(emb, det, [], 16000)
+    r1 = pipe.run(audio, bits, input_rate=44100)
+    assert int(r1.bit_errors) == 0 and abs(r1.seconds - 192.0) < 1e-9
+    key = next(k for k in pipe._sessions if not isinstance(k[0], str))
+    batch, sess = pipe._sessions[key]
+    assert batch.B == 64 and batch.frames[0] == 188
+    best = sess.best_loss.cpu().numpy()
+    assert np.all(best < 0.65) and np.all(np.isfinite(best))
+    lo, hi = sess.bounds
+    bc = sess.best_coef
+    assert bool(((bc >= lo) & (bc <= hi)).all())
+    assert bool((bc[:, 225:] == 0).all())                     # row padding stays zero
+    assert int(sess.step.cpu()[0]) == 400
+    w1 = r1.watermarked.data.clone()
+    r2 = pipe.run(audio, bits, input_rate=44100)
+    assert torch.equal(w1, r2.watermarked.data)
+    assert torch.equal(r1.values, r2.values)
+    # detector margin as in the reference (|raw| ~ 0.28-0.30 on marked audio)
+    assert float(r1.values.abs().min()) > 0.15
