@@ -418,7 +418,7 @@ static int det_forward(const aware_detector* d, const aware_batch* b, const floa
     o.tail = 0;
     for (int l = 0; l < d->n_layers; ++l) {
         const int ci = d->ch[l], co = d->ch[l + 1];
-        if (l == d->n_layers - 1 && co <= 64 && b->max_frames / 2 <= 128) {
+        if (l == d->n_layers - 1 && co <= 64 && b->max_frames / 2 <= 320) {
             // skinny last conv: split-K partial slabs, summed inside the fused tail kernel
             launch_gemm_nt_splitk(x, ci, d->w[l], ci, o.zpart, co, b->NP, co, ci, kTailSplit, st);
             LAUNCHCHK(); PROF(K_GEMM);
@@ -456,7 +456,7 @@ extern "C" int aware_detector_forward(const aware_detector* d, const aware_batch
     if (rc) return rc;
     if (o.tail)
         launch_tail(o.zpart, kTailSplit, (size_t)b->NP * d->ch[d->n_layers], d->bias[d->n_layers - 1], b->d_frame_off,
-                    b->d_pool_off, nullptr, values, nullptr, nullptr, nullptr, nullptr, nullptr, 0, d->nbits, b->B, st);
+                    b->d_pool_off, nullptr, values, nullptr, nullptr, nullptr, nullptr, nullptr, 0, d->nbits, b->B, b->max_frames / 2, st);
     else
         launch_head(o.act[d->n_layers - 1], b->d_frame_off, b->d_pool_off, nullptr, values, nullptr, nullptr, nullptr,
                     nullptr, nullptr, 0, d->nbits, b->B, st);
@@ -480,7 +480,7 @@ extern "C" int aware_detect(const aware_plan* plan, const aware_detector* d, con
     if (rc) return rc;
     if (o.tail)
         launch_tail(o.zpart, kTailSplit, (size_t)b->NP * d->ch[d->n_layers], d->bias[d->n_layers - 1], b->d_frame_off,
-                    b->d_pool_off, nullptr, values, nullptr, nullptr, nullptr, nullptr, nullptr, 0, d->nbits, b->B, st);
+                    b->d_pool_off, nullptr, values, nullptr, nullptr, nullptr, nullptr, nullptr, 0, d->nbits, b->B, b->max_frames / 2, st);
     else
         launch_head(o.act[d->n_layers - 1], b->d_frame_off, b->d_pool_off, nullptr, values, nullptr, nullptr, nullptr,
                     nullptr, nullptr, 0, d->nbits, b->B, st);
@@ -680,7 +680,8 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
     bool dz_ready = false;      // dA already holds dL/dZ of layer l (fused into the producing kernel)
     if (e->db.tail) {
         launch_tail(e->db.zpart, kTailSplit, (size_t)b->NP * d->ch[nl], d->bias[nl - 1], b->d_frame_off, b->d_pool_off,
-                    e->target, e->db.pred, e->loss, e->best_loss, e->improved, dA, step_ptr, e->cfg.loss, d->nbits, b->B, st);
+                    e->target, e->db.pred, e->loss, e->best_loss, e->improved, dA, step_ptr, e->cfg.loss, d->nbits, b->B,
+                    b->max_frames / 2, st);
         dz_ready = true;
     } else {
         launch_head(e->db.act[nl - 1], b->d_frame_off, b->d_pool_off, e->target, e->db.pred, e->loss, e->best_loss,

@@ -1006,21 +1006,20 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ a3,
 }
 
 // ---------------------------------------------------------------------------------
-// Fused tail of the detector for clips of up to 128 pooled frames: sum of the last conv's
+// Fused tail of the detector for clips of up to 4*R pooled frames (R = 32, or 80 for clips up to 10 s): sum of the last conv's
 // split-K partials + bias -> InstanceNorm -> LeakyReLU -> BRH read-out -> loss / best-loss
 // bookkeeping -> gradient back through the read-out, LeakyReLU and InstanceNorm.
 // One 256-thread workgroup per clip (64 channel slots x 4 row groups, activation in registers).
 // Writes pred, loss, improved, best_loss and dZ = dL/d(conv output) [rows][C]; advances the
 // optimiser step counter (block 0) when step != nullptr.
 // ---------------------------------------------------------------------------------
-template <int NSPLIT>
+template <int NSPLIT, int R>
 __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ zpart, size_t slab,
                                                     const float* __restrict__ bias, const int* __restrict__ frame_off,
                                                     const int* __restrict__ pool_off, const float* __restrict__ target,
                                                     float* __restrict__ pred, float* __restrict__ loss_out,
                                                     float* __restrict__ best_loss, int* __restrict__ improved,
                                                     float* __restrict__ dZ, int* __restrict__ step, int loss_kind, int nbits) {
-    constexpr int R = 32;
     __shared__ float red[4][64], red2[4][64], mean_s[64], dm[64];
     const int b = blockIdx.x, c = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int r0 = pool_off[b], Tp = (frame_off[b + 1] - frame_off[b]) / 2;
@@ -1133,16 +1132,13 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ zpa
 
 void launch_tail(const float* zpart, int nsplit, size_t slab, const float* bias, const int* frame_off, const int* pool_off,
                  const float* target, float* pred, float* loss, float* best_loss, int* improved, float* dZ, int* step,
-                 int loss_kind, int nbits, int B, hipStream_t st) {
-    if (nsplit == 4)
-        hipLaunchKernelGGL(tail_kernel<4>, dim3(B), dim3(256), 0, st, zpart, slab, bias, frame_off, pool_off, target, pred,
-                           loss, best_loss, improved, dZ, step, loss_kind, nbits);
-    else
-        hipLaunchKernelGGL(tail_kernel<1>, dim3(B), dim3(256), 0, st, zpart, slab, bias, frame_off, pool_off, target, pred,
-                           loss, best_loss, improved, dZ, step, loss_kind, nbits);
+                 int loss_kind, int nbits, int B, int max_pooled, hipStream_t st) {
+#define TL(S_, R_) hipLaunchKernelGGL((tail_kernel<S_, R_>), dim3(B), dim3(256), 0, st, zpart, slab, bias, frame_off, pool_off, \
+                                      target, pred, loss, best_loss, improved, dZ, step, loss_kind, nbits)
+    if (max_pooled <= 128) { if (nsplit == 4) TL(4, 32); else TL(1, 32); }
+    else { if (nsplit == 4) TL(4, 80); else TL(1, 80); }
+#undef TL
 }
-
-
 void launch_mel_norm_fwd(const float* xm, const int* frame_off, const int* pool_off, float* x0, float* stats,
                          float* gstat, float* part, int pstride, int B, int max_frames, hipStream_t st) {
     const int nx = (max_frames + kMelChunk - 1) / kMelChunk;
@@ -1160,6 +1156,8 @@ void launch_mel_norm_bwd(const float* dx0, float* xm, const int* frame_off, cons
 void launch_in_lrelu_fwd(float* z, const int* frame_off, const int* pool_off, float* rstd, int C, int B, int max_pooled, hipStream_t st) {
     if (max_pooled <= 128)
         hipLaunchKernelGGL(in_lrelu_fwd_reg_kernel<32>, dim3((C + 63) / 64, B), dim3(256), 0, st, z, frame_off, pool_off, rstd, C);
+    else if (max_pooled <= 320)
+        hipLaunchKernelGGL(in_lrelu_fwd_reg_kernel<80>, dim3((C + 63) / 64, B), dim3(256), 0, st, z, frame_off, pool_off, rstd, C);
     else
         hipLaunchKernelGGL(in_lrelu_fwd_kernel, dim3((C + 63) / 64, B), dim3(256), 0, st, z, frame_off, pool_off, rstd, C);
 }
@@ -1167,6 +1165,8 @@ void launch_in_lrelu_bwd(float* dA, const float* A, const int* frame_off, const 
                          int max_pooled, hipStream_t st) {
     if (max_pooled <= 128)
         hipLaunchKernelGGL(in_lrelu_bwd_reg_kernel<32>, dim3((C + 63) / 64, B), dim3(256), 0, st, dA, A, frame_off, pool_off, rstd, C);
+    else if (max_pooled <= 320)
+        hipLaunchKernelGGL(in_lrelu_bwd_reg_kernel<80>, dim3((C + 63) / 64, B), dim3(256), 0, st, dA, A, frame_off, pool_off, rstd, C);
     else
         hipLaunchKernelGGL(in_lrelu_bwd_kernel, dim3((C + 63) / 64, B), dim3(256), 0, st, dA, A, frame_off, pool_off, rstd, C);
 }

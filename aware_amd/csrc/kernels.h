@@ -97,7 +97,7 @@ void launch_gemm_nt_splitk(const float* A, int lda, const float* Bt, int ldb, fl
                            int ksplit, hipStream_t st);
 void launch_tail(const float* zpart, int nsplit, size_t slab, const float* bias, const int* frame_off, const int* pool_off,
                  const float* target, float* pred, float* loss, float* best_loss, int* improved, float* dZ, int* step,
-                 int loss_kind, int nbits, int B, hipStream_t st);
+                 int loss_kind, int nbits, int B, int max_pooled, hipStream_t st);
 
 // ---- attack_kernels.hip -----------------------------------------------------------------
 void launch_pcm_quantize(const float* in, float* out, const int* off, const int* len, const unsigned long long* pmax,
