@@ -35,6 +35,24 @@ class WatermarkPipeline:
         self.attack_mode = attack_mode
         self._sessions = {}
 
+    def prepare(self, lengths_16k, input_rate: int | None = None):
+        """One-time set-up for a batch geometry (lengths at the pipeline's 16 kHz): geometry tables,
+        workspace, measured GEMM tile choice, hipGraph capture, resampler design.  Not part of a step."""
+        key = tuple(int(n) for n in lengths_16k)
+        if key not in self._sessions:
+            b = rt.Batch(list(key))
+            self._sessions[key] = (b, self.embedder.start_session(b, self.sample_rate))
+        batch, sess = self._sessions[key]
+        sess.iterate(0)                                    # records the graphs without running them
+        dkey = ("det",) + tuple(batch.out_lengths)
+        if dkey not in self._sessions:
+            self._sessions[dkey] = rt.Batch(batch.out_lengths)
+        if input_rate and input_rate != self.sample_rate:
+            from .attacks import _resample_filter
+            g = int(np.gcd(self.sample_rate, input_rate))
+            _resample_filter(self.sample_rate // g, input_rate // g, torch.device("cuda", torch.cuda.current_device()))
+        return batch
+
     @staticmethod
     def _clip_max(x: "rt.Ragged") -> torch.Tensor:
         """signed per-clip maximum (service/embed.py:69)"""

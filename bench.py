@@ -102,6 +102,8 @@ def main():
     pipe = WatermarkPipeline(embedder, detector, attacks, sample_rate=16000, attack_mode="chain")
     audio, bits = synthetic_clips(per_gpu, args.seconds, 44100, first_seed=rank * per_gpu, device=dev)
 
+    n16 = -(-int(round(args.seconds * 44100)) * 160 // 441)        # clip length after the 44.1k -> 16k front end
+    pipe.prepare([n16] * per_gpu, input_rate=44100)                # set-up (tables, tile choice, graphs), not a step
     log(f"rank {rank}/{world}: {per_gpu} clips x {args.seconds} s resident on {dev}; warm-up x{args.warmup}")
     for _ in range(args.warmup):
         res = pipe.run(audio, bits, input_rate=44100)
