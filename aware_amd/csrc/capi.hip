@@ -534,7 +534,7 @@ extern "C" int aware_embed_create(aware_embed** out, const aware_plan* plan, con
                                   const aware_batch* b, const aware_embed_config* cfg, void* workspace,
                                   size_t workspace_bytes, void* stream) {
     if (!out || !plan || !det || !b || !cfg || !workspace) return AWARE_E_BADARG;
-    if (cfg->num_iterations < 1 || cfg->num_iterations > 4096 || cfg->loss < 0 || cfg->loss > 3) return AWARE_E_BADARG;
+    if (cfg->num_iterations < 1 || cfg->num_iterations > 4096 || cfg->loss < 0 || cfg->loss > 5) return AWARE_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     aware_embed* e = new aware_embed();
     e->plan = plan; e->det = det; e->b = b; e->cfg = *cfg;

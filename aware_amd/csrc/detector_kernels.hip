@@ -938,7 +938,7 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_kernel(float* __restrict__ d
 
 // ---------------------------------------------------------------------------------
 // BRH read-out + loss + gradient seed.  One 64-thread workgroup per clip.
-// loss_kind: 0 push_extremes, 1 mse, 2 hinge, 3 sign  (embedding/losses.py)
+// loss_kind: 0 push_extremes, 1 mse, 2 hinge, 3 sign, 4 push_sigmoid, 5 ber  (embedding/losses.py)
 // If dA3 == nullptr only the prediction is produced (detect path).
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ a3, const int* __restrict__ frame_off, const int* __restrict__ pool_off,
@@ -974,10 +974,17 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ a3,
                 float h = 1.f - p * tg;
                 lterm = (h > 0.f ? h : 0.f) * inv;
                 dp = (h > 0.f ? -tg : 0.f) * inv;
-            } else {
+            } else if (loss_kind == 3) {
                 float h = -p * tg;
                 lterm = (h > 0.f ? h : 0.f) * inv;
                 dp = (h > 0.f ? -tg : 0.f) * inv;
+            } else if (loss_kind == 4) {            // push_sigmoid: mse - 0.1*mean|p - 0.5|  (losses.py:55-59)
+                lterm = ((p - tg) * (p - tg) - 0.1f * fabsf(p - 0.5f)) * inv;
+                dp = (2.f * (p - tg) - 0.1f * ((p > 0.5f) ? 1.f : (p < 0.5f ? -1.f : 0.f))) * inv;
+            } else {                                // ber: mean(sign(p) != sign(t)), no gradient  (losses.py:90-92)
+                const float sp = (p > 0.f) ? 1.f : (p < 0.f ? -1.f : 0.f), st_ = (tg > 0.f) ? 1.f : (tg < 0.f ? -1.f : 0.f);
+                lterm = (sp != st_ ? 1.f : 0.f) * inv;
+                dp = 0.f;
             }
         }
     }
@@ -1084,10 +1091,17 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ zpa
                 float h = 1.f - p * tg;
                 lterm = (h > 0.f ? h : 0.f) * inv;
                 dp = (h > 0.f ? -tg : 0.f) * inv;
-            } else {
+            } else if (loss_kind == 3) {
                 float h = -p * tg;
                 lterm = (h > 0.f ? h : 0.f) * inv;
                 dp = (h > 0.f ? -tg : 0.f) * inv;
+            } else if (loss_kind == 4) {            // push_sigmoid: mse - 0.1*mean|p - 0.5|  (losses.py:55-59)
+                lterm = ((p - tg) * (p - tg) - 0.1f * fabsf(p - 0.5f)) * inv;
+                dp = (2.f * (p - tg) - 0.1f * ((p > 0.5f) ? 1.f : (p < 0.5f ? -1.f : 0.f))) * inv;
+            } else {                                // ber: mean(sign(p) != sign(t)), no gradient  (losses.py:90-92)
+                const float sp = (p > 0.f) ? 1.f : (p < 0.f ? -1.f : 0.f), st_ = (tg > 0.f) ? 1.f : (tg < 0.f ? -1.f : 0.f);
+                lterm = (sp != st_ ? 1.f : 0.f) * inv;
+                dp = 0.f;
             }
         }
     }

@@ -52,10 +52,27 @@ class SignBasedLoss(_KernelLoss):
         return torch.mean(torch.clamp(-predicted * target_pattern, min=0))
 
 
-registry = {"hinge": HingeLoss, "mse": MSELoss, "push_extremes": PushToExtremesLoss, "sign": SignBasedLoss}
-# names the reference registers for sigmoid-output / non-differentiable variants (losses.py:99-102);
-# its own detector ends in tanh, so they are not part of the hot path
-_NOT_ON_HIP = ("push_sigmoid", "bce", "ber")
+class PushToExtremesSigmoidLoss(_KernelLoss):
+    """mse - 0.1 * mean|pred - 0.5|  (losses.py:55-59)"""
+    kernel_id, name = 4, "push_sigmoid"
+
+    def forward(self, predicted, target_pattern):
+        return torch.mean((predicted - target_pattern) ** 2) - 0.1 * torch.mean(torch.abs(predicted - 0.5))
+
+
+class BERLoss(_KernelLoss):
+    """mean(sign(pred) != sign(target)); piecewise constant, zero gradient  (losses.py:90-92)"""
+    kernel_id, name = 5, "ber"
+
+    def forward(self, predicted, target_pattern):
+        return torch.mean((torch.sign(predicted) != torch.sign(target_pattern)).float())
+
+
+registry = {"hinge": HingeLoss, "mse": MSELoss, "push_extremes": PushToExtremesLoss, "push_sigmoid": PushToExtremesSigmoidLoss,
+            "sign": SignBasedLoss, "ber": BERLoss}
+# F.binary_cross_entropy needs predictions in [0, 1]; the detector ends in tanh, so the reference's
+# "bce" entry (losses.py:79-81) raises inside torch for its own model card -- refused here by name
+_NOT_ON_HIP = ("bce",)
 
 
 def get_loss_fn(loss_type: str, **kwargs) -> Loss:

@@ -16,7 +16,7 @@ from ._lib import EmbedConfig, check, load_library, require_gpu
 
 SPEC_STRIDE = 256
 FULL_STRIDE = 520
-LOSS_KINDS = {"push_extremes": 0, "mse": 1, "hinge": 2, "sign": 3}
+LOSS_KINDS = {"push_extremes": 0, "mse": 1, "hinge": 2, "sign": 3, "push_sigmoid": 4, "ber": 5}
 
 
 def _stream():

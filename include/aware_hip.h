@@ -112,8 +112,8 @@ int aware_detector_forward(const aware_detector* det, const aware_batch* batch, 
 
 /* ---- embedder -----------------------------------------------------------------------------------
  * AWAREEmbedder.embed / _optimize (embedding/multibit_embedder.py:70-197), batched and ragged:
- * every clip is its own optimisation problem.  loss: 0 push_extremes, 1 mse, 2 hinge, 3 sign
- * (embedding/losses.py:95-103).  optimizer: NAdam (embedding/optimizers.py:5; torch.optim.NAdam
+ * every clip is its own optimisation problem.  loss: 0 push_extremes, 1 mse, 2 hinge, 3 sign,
+ * 4 push_sigmoid, 5 ber (no gradient) (embedding/losses.py:95-103; bce needs sigmoid outputs).  optimizer: NAdam (embedding/optimizers.py:5; torch.optim.NAdam
  * single-tensor semantics) with lr, beta1, beta2, eps, momentum_decay; the reference's
  * ReduceLROnPlateau(patience 500) never fires within 400 iterations and is not modelled. */
 typedef struct aware_embed_config {

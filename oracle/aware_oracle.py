@@ -235,6 +235,8 @@ LOSSES = {
     "mse": lambda p, t: ((p - t) ** 2).mean(dim=-1),
     "push_extremes": push_extremes_loss,
     "sign": lambda p, t: torch.clamp(-p * t, min=0).mean(dim=-1),
+    "push_sigmoid": lambda p, t: ((p - t) ** 2).mean(dim=-1) - 0.1 * (p - 0.5).abs().mean(dim=-1),
+    "ber": lambda p, t: (torch.sign(p) != torch.sign(t)).float().mean(dim=-1) + 0.0 * p.sum(dim=-1),
 }
 
 

@@ -186,7 +186,7 @@ def test_losses_and_windows_first_gradient(models):
     plan = get_plan()
     dw = emb.detection_net.device_weights(plan)
     batch = rt.Batch([16000])
-    for loss in ("mse", "hinge", "sign"):
+    for loss in ("mse", "hinge", "sign", "push_sigmoid", "ber"):
         sess = rt.EmbedSession(plan, dw, batch, loss=loss, use_graph=False)
         sess.begin(batch.pack([audio]), torch.from_numpy(wm[None]).cuda())
         g = sess.gradient().cpu()[:, :225].T

@@ -120,6 +120,7 @@ def test_registries_raise_like_the_reference():
     assert get_loss_fn("hinge").kernel_id == 2
     with pytest.raises(NotImplementedError):
         get_loss_fn("bce")
+    assert get_loss_fn("ber").kernel_id == 5 and get_loss_fn("push_sigmoid").kernel_id == 4
     with pytest.raises(ValueError, match="not found"):
         get_optimizer("nope")
     with pytest.raises(NotImplementedError):
