@@ -258,3 +258,24 @@ def test_full_size_config1_properties(models):
     assert torch.equal(r1.values, r2.values)
     # detector margin as in the reference (|raw| ~ 0.28-0.30 on marked audio)
     assert float(r1.values.abs().min()) > 0.15
+
+
+def test_degenerate_inputs_stay_finite(models):
+    """Silence and the shortest legal clip go through a few optimiser iterations without NaN/Inf
+    (zero variance in every InstanceNorm, zero gradients into NAdam, a single pooled frame)."""
+    from aware_amd import runtime as rt
+    emb, det = models
+    lens = [16000, 513, 16000]
+    clips = [np.zeros(16000, dtype=np.float32), make_clip(80, 513)[0], make_clip(81, 16000)[0]]
+    batch = rt.Batch(lens)
+    sess = emb.start_session(batch, 16000)
+    wm = torch.ones((3, 20), device="cuda")
+    sess.begin(batch.pack(clips), wm)
+    sess.iterate(5)
+    out = sess.finish(None)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out).all())
+    assert bool(torch.isfinite(sess.loss).all()) and bool(torch.isfinite(sess.coef).all())
+    o = batch.unpack_out(out)
+    assert float(o[0].abs().max()) == 0.0                 # silence stays silence
+    assert [x.numel() for x in o] == [15872, 512, 15872]
