@@ -305,12 +305,14 @@ __global__ __launch_bounds__(kThreads) void synth_kernel(SynthArgs a) {
     cn.m = 1.f; cn.m2 = 1.f; cn.k = 0;
     if (MODE == SY_ADJ) cn = clip_norm_from_partials(a.pmax_in + (size_t)b * a.pstride, a.pcount[b], red);
 
+    // twiddles live in LDS in this kernel (28 VGPRs less per lane -> one more wave per SIMD)
+    __shared__ cf tw1s[512];
+    __shared__ cf tw2s[64];
+    fft_fill_tables(tid, kThreads, a.plan.tw512, tw1s, tw2s);
     for (int i = tid; i < kChunk; i += kThreads) ola[i] = 0.f;
     __syncthreads();
 
     cf* s = scratch[wave];
-    FftLaneConst fc;
-    fft_lane_const(lane, a.plan.tw512, fc);
     // irfft's 1/1024 (1/2 in the merge, 1/512 here); the adjoint of the forward rfft is 512*irfft
     const float scale = (MODE == SY_FWD) ? (1.0f / 512.0f) : 1.0f;
     const float2* win2p = reinterpret_cast<const float2*>(a.plan.window);   // 4 KB, L1-resident
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(kThreads) void synth_kernel(SynthArgs a) {
                     v[r] = irfft_merge_bin(k, xk, xp, a.plan.tw1024);
                 }
             }
-            fft512_wave<1>(lane, v, fc, s);
+            fft512_wave_t<1>(lane, v, tw1s, tw2s, s);
             float2* o2 = reinterpret_cast<float2*>(ola + kHop * fi);
 #pragma unroll
             for (int r = 0; r < 8; ++r) {

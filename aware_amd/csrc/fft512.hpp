@@ -112,6 +112,31 @@ template <int DIR> AW_HD void fft_phaseC(int lane, cf (&v)[8], cf* s) {
     radix8<DIR>(v);
 }
 
+// ---- the same phases with the twiddles read from LDS tables instead of registers ---------
+// (28 VGPRs less per lane; tw1s[k0*64 + lane] = W512^(lane*k0), tw2s[n0*8 + q0] = W64^(n0*q0);
+// consecutive lanes read consecutive words / lanes with equal n0 broadcast: conflict-free)
+template <int DIR> AW_HD void fft_phaseA_t(int lane, cf (&v)[8], const cf* tw1s, cf* s) {
+    radix8<DIR>(v);
+#pragma unroll
+    for (int k0 = 0; k0 < 8; ++k0) {
+        cf w = (k0 == 0) ? v[0] : cmul(v[k0], tw_dir<DIR>(tw1s[k0 * 64 + lane]));
+        s[k0 * 72 + lane] = w;
+    }
+}
+template <int DIR> AW_HD void fft_phaseB_t(int lane, cf (&v)[8], const cf* tw2s, cf* s) {
+    const int k0 = lane >> 3, n0 = lane & 7;
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) v[n1] = s[k0 * 72 + 8 * n1 + n0];
+    radix8<DIR>(v);
+#pragma unroll
+    for (int q0 = 1; q0 < 8; ++q0) v[q0] = cmul(v[q0], tw_dir<DIR>(tw2s[n0 * 8 + q0]));
+}
+// fill the two tables (all threads of the block; caller synchronises)
+AW_HD void fft_fill_tables(int tid, int nthreads, const cf* tw512, cf* tw1s, cf* tw2s) {
+    for (int i = tid; i < 512; i += nthreads) tw1s[i] = tw512[((i & 63) * (i >> 6)) & 511];
+    for (int i = tid; i < 64; i += nthreads) tw2s[i] = tw512[(8 * (i >> 3) * (i & 7)) & 511];
+}
+
 // ---- real-FFT split (forward) -----------------------------------------------------
 // After the forward complex FFT, lane L reg r holds Z[L+64r].  X[k], k = 0..511:
 //   X[k] = E - i*W^k*D,  E = (Z[k] + conj Z[512-k])/2,  D = (Z[k] - conj Z[512-k])/2
@@ -162,6 +187,17 @@ __device__ __forceinline__ void fft512_wave(int lane, cf (&v)[8], const FftLaneC
     fft_phaseA<DIR>(lane, v, c, s);
     wave_sync();
     fft_phaseB<DIR>(lane, v, c, s);
+    wave_sync();
+    fft_phaseB_store<DIR>(lane, v, s);
+    wave_sync();
+    fft_phaseC<DIR>(lane, v, s);
+    wave_sync();
+}
+template <int DIR>
+__device__ __forceinline__ void fft512_wave_t(int lane, cf (&v)[8], const cf* tw1s, const cf* tw2s, cf* s) {
+    fft_phaseA_t<DIR>(lane, v, tw1s, s);
+    wave_sync();
+    fft_phaseB_t<DIR>(lane, v, tw2s, s);
     wave_sync();
     fft_phaseB_store<DIR>(lane, v, s);
     wave_sync();
