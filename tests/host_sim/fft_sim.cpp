@@ -12,6 +12,17 @@ using namespace aware;
 
 static std::vector<cf> tw512(512), tw1024(512);
 
+// the LDS-table form used by the synthesis kernels
+template <int DIR>
+static void fft512_sim_tables(cf (*V)[8], cf* s) {
+    std::vector<cf> t1(512), t2(64);
+    for (int tid = 0; tid < 256; ++tid) fft_fill_tables(tid, 256, tw512.data(), t1.data(), t2.data());
+    for (int l = 0; l < 64; ++l) fft_phaseA_t<DIR>(l, V[l], t1.data(), s);
+    for (int l = 0; l < 64; ++l) fft_phaseB_t<DIR>(l, V[l], t2.data(), s);
+    for (int l = 0; l < 64; ++l) fft_phaseB_store<DIR>(l, V[l], s);
+    for (int l = 0; l < 64; ++l) fft_phaseC<DIR>(l, V[l], s);
+}
+
 template <int DIR>
 static void fft512_sim(cf (*V)[8], cf* s) {
     FftLaneConst c[64];
@@ -71,7 +82,7 @@ int main() {
             if (k == 0) { xk.y = 0; xp.y = 0; }
             V[l][r] = irfft_merge_bin(k, xk, xp, tw1024.data());
         }
-    fft512_sim<1>(V, s.data());
+    fft512_sim_tables<1>(V, s.data());
     double maxerr_i = 0;
     for (int l = 0; l < 64; ++l)
         for (int r = 0; r < 8; ++r) {
