@@ -346,11 +346,11 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_clip_kernel(const float* 
         }
     };
     const int nk = (K + BK - 1) / BK;
-    gload(0);
-    sstore(0);
-    if (nk > 1) gload(BK);
-    __syncthreads();
     if (DB == 2) {
+        gload(0);
+        sstore(0);
+        if (nk > 1) gload(BK);
+        __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
             compute(cur);
@@ -361,13 +361,51 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_clip_kernel(const float* 
             __syncthreads();
         }
     } else {
-        for (int kt = 0; kt < nk; ++kt) {
-            compute(0);
+        // one LDS buffer, TWO register sets: the loads of K tile kt+2 and kt+3 are in flight while tile kt
+        // is consumed, so a load has two tile periods to land before its s_waitcnt (two tiles per trip to
+        // keep the register sets statically indexed)
+        float4 ra2[LA], rb2[LB];
+        auto gload2 = [&](int k0) {
+#pragma unroll
+            for (int i = 0; i < LA; ++i) {
+                int rl = lrow + RPP * i, k = k0 + lkq;
+                const bool ok = (BM % RPP == 0 || rl < BM) && (EXACT || k < K);
+                ra2[i] = ok ? *reinterpret_cast<const float4*>(A + (size_t)(bm + rl) * lda + k) : make_float4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < LB; ++i) {
+                int rl = lrow + RPP * i, r = bn + rl, k = k0 + lkq;
+                const bool ok = (BN % RPP == 0 || rl < BN) && (EXACT || (r < N && k < K));
+                rb2[i] = ok ? *reinterpret_cast<const float4*>(Bt + (size_t)r * ldb + k) : make_float4(0, 0, 0, 0);
+            }
+        };
+        auto sstore2 = [&]() {
+#pragma unroll
+            for (int i = 0; i < LA; ++i)
+                if (lrow + RPP * i < BM) *reinterpret_cast<float4*>(&As[0][(lrow + RPP * i) * LD + lkq]) = ra2[i];
+#pragma unroll
+            for (int i = 0; i < LB; ++i)
+                if (lrow + RPP * i < BN) *reinterpret_cast<float4*>(&Bs[0][(lrow + RPP * i) * LD + lkq]) = rb2[i];
+        };
+        gload(0);
+        sstore(0);
+        if (nk > 1) gload(BK);            // set 1 <- tile 1
+        if (nk > 2) gload2(2 * BK);       // set 2 <- tile 2
+        __syncthreads();
+        for (int kt = 0; kt < nk; kt += 2) {
+            compute(0);                                   // tile kt
             __syncthreads();
             if (kt + 1 < nk) {
-                sstore(0);
-                if (kt + 2 < nk) gload((kt + 2) * BK);
+                sstore(0);                                // tile kt+1 (set 1)
+                if (kt + 3 < nk) gload((kt + 3) * BK);    // set 1 <- tile kt+3
                 __syncthreads();
+                compute(0);                               // tile kt+1
+                __syncthreads();
+                if (kt + 2 < nk) {
+                    sstore2();                            // tile kt+2 (set 2)
+                    if (kt + 4 < nk) gload2((kt + 4) * BK);   // set 2 <- tile kt+4
+                    __syncthreads();
+                }
             }
         }
     }
