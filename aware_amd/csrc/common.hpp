@@ -26,14 +26,8 @@ struct PlanDev {
     int nband;            // number of band bins (225)
 };
 
-// A ragged batch of clips.  frame_off has B+1 entries (prefix sums of T_b).
 // A clip's "istft-length" signal (Ny_b = 256*(T_b-1) samples) lives at float offset
-// 256*(frame_off[b] - b) of any per-clip signal array.
-struct Batch {
-    const int* frame_off;
-    int B;
-};
-
+// 256*(frame_off[b] - b) of any per-clip signal array (frame_off: B+1 prefix sums of T_b).
 __device__ __forceinline__ int sig_offset(const int* frame_off, int b) { return kHop * (frame_off[b] - b); }
 
 // per-clip maximum of |y| with the first index attaining it, packed so that an

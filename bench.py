@@ -175,6 +175,10 @@ def main():
                             "unit": "GB/s", "frac": round(dsp_bytes / (dsp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                             "avg_launch_us": round(dsp_ms * 1e3 / (4 * n_it), 2)}}
 
+    if world > 1:
+        import torch.distributed as dist
+        parallel.barrier()
+        dist.destroy_process_group()
     if rank != 0:
         return
     value = sums["seconds"] / maxes["wall"]
