@@ -105,6 +105,9 @@ def load_library():
         raise AwareHipError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  aware_amd has no CPU fallback.")
+    # torch first: PyTorch-ROCm ships its own HIP runtime (libamdhip64); loading it before this library
+    # makes both resolve to the same runtime instance, so device pointers and streams are interchangeable
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
