@@ -168,3 +168,32 @@ def test_shard_by_cost_balances_and_is_deterministic():
     assert (max(loads) - min(loads)) / np.mean(loads) < 0.01
     assert shards == shard_by_cost(costs, 8)
     assert shard_by_cost([5, 1], 1) == [[0, 1]]
+
+
+def test_product_code_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under aware_amd/ (nor bench.py outside its
+    cpu_baseline leg) may import it."""
+    import ast
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "aware_amd")):
+        for f in files:
+            if not f.endswith(".py"):
+                continue
+            tree = ast.parse(open(os.path.join(dirpath, f)).read())
+            for node in ast.walk(tree):
+                names = []
+                if isinstance(node, ast.Import):
+                    names = [a.name for a in node.names]
+                elif isinstance(node, ast.ImportFrom):
+                    names = [node.module or ""]
+                if any(n == "oracle" or n.startswith("oracle.") for n in names):
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, bad
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tree = ast.parse(src)
+    for node in tree.body:                                   # no module-level oracle import in bench.py
+        if isinstance(node, (ast.Import, ast.ImportFrom)):
+            mod = getattr(node, "module", None) or ""
+            assert not mod.startswith("oracle") and all(not a.name.startswith("oracle") for a in node.names)
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "cpu_baseline")
+    assert any(isinstance(n, ast.ImportFrom) and (n.module or "").startswith("oracle") for n in ast.walk(fn))

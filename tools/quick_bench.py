@@ -3,7 +3,7 @@ import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from aware_amd import runtime as rt
-from oracle import aware_oracle as O
+from aware_amd.detection import AWAREDetectorNet
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 50
@@ -12,8 +12,7 @@ n = 48000
 plan = rt.Plan()
 if len(sys.argv) > 4:
     plan.lib.aware_tune(1, int(sys.argv[4]))
-ws, bs = O.detector_weights()
-det = rt.DetectorWeights(plan, O.mel_filter_bank(), [w.numpy() for w in ws], [b.numpy() for b in bs])
+det = AWAREDetectorNet().device_weights(plan)
 batch = rt.Batch([n] * B)
 g = torch.Generator(device="cuda").manual_seed(0)
 audio = 0.1 * torch.randn(B * n, device="cuda", generator=g)

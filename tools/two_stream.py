@@ -3,12 +3,11 @@ import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from aware_amd import runtime as rt
-from oracle import aware_oracle as O
+from aware_amd.detection import AWAREDetectorNet
 B = int(sys.argv[1]); iters = int(sys.argv[2]); nsplit = int(sys.argv[3])
 n = 48000
 plan = rt.Plan()
-ws, bs = O.detector_weights()
-det = rt.DetectorWeights(plan, O.mel_filter_bank(), [w.numpy() for w in ws], [b.numpy() for b in bs])
+det = AWAREDetectorNet().device_weights(plan)
 g = torch.Generator(device="cuda").manual_seed(0)
 streams = [torch.cuda.Stream() for _ in range(nsplit)]
 sess = []
