@@ -1,4 +1,5 @@
+"""Host-side helpers: logger, YAML card loading, ndarray -> tensor."""
+from .utils import to_tensor, load_config
 from .logger import logger
-from .utils import load_config, to_tensor
 
-__all__ = ["logger", "load_config", "to_tensor"]
+__all__ = ["load_config", "to_tensor", "logger"]

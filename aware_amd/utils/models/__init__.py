@@ -1,3 +1,4 @@
-from .load_model import load
+"""Factory: `load()` builds the (embedder, detector) pair from cards/config.yaml."""
+from .load_model import load  # noqa: F401
 
-__all__ = ["load"]
+__all__ = ("load",)

@@ -1,3 +1,4 @@
-from .codec import PatternEncoder, PatternDecoder
+"""Watermark pattern codec (bits / bytes <-> bipolar)."""
+from .codec import PatternDecoder, PatternEncoder  # noqa: F401
 
-__all__ = ["PatternEncoder", "PatternDecoder"]
+__all__ = ("PatternEncoder", "PatternDecoder")
