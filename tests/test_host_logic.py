@@ -197,3 +197,15 @@ def test_product_code_never_imports_the_oracle():
             assert not mod.startswith("oracle") and all(not a.name.startswith("oracle") for a in node.names)
     fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "cpu_baseline")
     assert any(isinstance(n, ast.ImportFrom) and (n.module or "").startswith("oracle") for n in ast.walk(fn))
+
+
+def test_aware_alias_package():
+    """`aware.*` (the reference's import names) resolves to aware_amd.*"""
+    from aware.utils.models import load
+    from aware.service import embed_watermark, detect_watermark
+    from aware.utils.watermark import PatternEncoder
+    import aware_amd.service
+    assert embed_watermark is aware_amd.service.embed_watermark
+    assert detect_watermark is aware_amd.service.detect_watermark
+    emb, det = load()
+    assert type(emb).__name__ == "AWAREEmbedder" and PatternEncoder().mode == "bits2bipolar"
