@@ -11,9 +11,9 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaware_hip.so")
+LIB_PATH = os.environ.get("AWARE_HIP_LIB") or os.path.join(_HERE, "libaware_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["capi.hip", "dsp_kernels.hip", "detector_kernels.hip", "attack_kernels.hip"]
+SOURCES = ["capi.hip", "dsp_kernels.hip", "detector_kernels.hip", "gemm_x3.hip", "attack_kernels.hip"]
 
 AWARE_OK = 0
 ERRORS = {-1: "bad argument", -2: "unsupported configuration", -3: "HIP runtime error", -4: "workspace too small"}
@@ -90,6 +90,9 @@ SIGNATURES = {
     "aware_gaussian_noise": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _f, _vp, _vp]),
     "aware_spectral_quantize": (_i, [_vp, _i, _f, _f, _vp]),
     "aware_gemm_nt_variant": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "aware_x3_packed_bytes": (_sz, [_i, _i]),
+    "aware_x3_pack": (_i, [_vp, _i, _i, _vp]),
+    "aware_gemm_clip": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "aware_gemm_nt": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
 }
 

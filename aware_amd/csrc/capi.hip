@@ -46,7 +46,7 @@ static inline void prof_mark(int kind) {
 #define PROF(kind) prof_mark(kind)
 // kernel kinds reported by aware_embed_profile
 enum { K_SYNTH = 0, K_ANALYSIS = 1, K_GEMM = 2, K_MELNORM = 3, K_INLRELU = 4, K_HEAD = 5, K_SYNTH_ADJ = 6,
-       K_ANALYSIS_ADJ = 7, K_MISC = 8, K_GEMM_CLIP_FWD = 9, K_GEMM_CLIP_BWD = 10 };
+       K_ANALYSIS_ADJ = 7, K_MISC = 8, K_GEMM_CLIP_FWD = 9, K_GEMM_CLIP_BWD = 10, K_GEMM_X3_FWD = 11, K_GEMM_X3_BWD = 12 };
 
 static int absmax_into_scratch(const float* in, const int* off, const int* len, int B, int max_len, void* scratch,
                                unsigned long long** pmax_out, int** pcount_out, int* ps_out, hipStream_t st);
@@ -77,6 +77,11 @@ struct aware_detector {
     float* melB = nullptr;   // [256][n_mels]  (Bt of its data-gradient)
     float* w[8] = {nullptr};   // [Cout][Cin]
     float* wT[8] = {nullptr};  // [Cin][Cout]
+    // the same two operands split into three bf16 planes in MFMA fragment order (gemm_x3.hip); null when the
+    // shape is not served by that kernel
+    void* wpk[8] = {nullptr};
+    void* wTpk[8] = {nullptr};
+    void* pkmem = nullptr;
     float* bias[8] = {nullptr};
 };
 
@@ -353,12 +358,34 @@ extern "C" int aware_detector_create(aware_detector** out, const aware_plan* pla
     d->melT = d->mem + o_melT;
     d->melB = d->mem + o_melB;
     for (int l = 0; l < n_layers; ++l) { d->w[l] = d->mem + o_w[l]; d->wT[l] = d->mem + o_wT[l]; d->bias[l] = d->mem + o_b[l]; }
+    {
+        size_t pk_total = 0, o_pk[8], o_pkT[8];
+        for (int l = 0; l < n_layers; ++l) {
+            const int ci = channels[l], co = channels[l + 1];
+            o_pk[l] = o_pkT[l] = (size_t)-1;
+            if (co % 128 == 0 && ci % 64 == 0) { o_pk[l] = pk_total; pk_total += x3_packed_bytes(co, ci); }
+            if (ci % 128 == 0 && co % 64 == 0) { o_pkT[l] = pk_total; pk_total += x3_packed_bytes(ci, co); }
+        }
+        std::vector<uint16_t> hp(pk_total / 2 + 8, 0);
+        for (int l = 0; l < n_layers; ++l) {
+            const int ci = channels[l], co = channels[l + 1];
+            if (o_pk[l] != (size_t)-1) x3_pack(h.data() + o_w[l], co, ci, hp.data() + o_pk[l] / 2);
+            if (o_pkT[l] != (size_t)-1) x3_pack(h.data() + o_wT[l], ci, co, hp.data() + o_pkT[l] / 2);
+        }
+        HIPCHK(hipMalloc(&d->pkmem, pk_total + 16));
+        HIPCHK(hipMemcpy(d->pkmem, hp.data(), pk_total, hipMemcpyHostToDevice));
+        for (int l = 0; l < n_layers; ++l) {
+            if (o_pk[l] != (size_t)-1) d->wpk[l] = (char*)d->pkmem + o_pk[l];
+            if (o_pkT[l] != (size_t)-1) d->wTpk[l] = (char*)d->pkmem + o_pkT[l];
+        }
+    }
     *out = d;
     return AWARE_OK;
 }
 extern "C" void aware_detector_destroy(aware_detector* d) {
     if (!d) return;
     if (d->mem) (void)hipFree(d->mem);
+    if (d->pkmem) (void)hipFree(d->pkmem);
     delete d;
 }
 
@@ -425,9 +452,15 @@ static int det_forward(const aware_detector* d, const aware_batch* b, const floa
             o.tail = 1;
         } else if (nwm && co >= 128) {
             // conv + InstanceNorm + LeakyReLU in one kernel (clip-aligned tiles)
-            launch_gemm_clip(x, ci, d->w[l], ci, d->bias[l], o.act[l], co, b->B, nwm, b->uniform_tp, co, ci, 1, o.rstd[l],
-                             nullptr, st);
-            LAUNCHCHK(); PROF(K_GEMM_CLIP_FWD);
+            if (get_gemm_clip_config() == 4 && d->wpk[l] && gemm_clip_x3_supported(nwm, co, ci, ci)) {
+                launch_gemm_clip_x3(x, ci, d->wpk[l], d->bias[l], o.act[l], co, b->B, nwm, b->uniform_tp, co, ci, 1, o.rstd[l],
+                                    nullptr, st);
+                LAUNCHCHK(); PROF(K_GEMM_X3_FWD);
+            } else {
+                launch_gemm_clip(x, ci, d->w[l], ci, d->bias[l], o.act[l], co, b->B, nwm, b->uniform_tp, co, ci, 1, o.rstd[l],
+                                 nullptr, st);
+                LAUNCHCHK(); PROF(K_GEMM_CLIP_FWD);
+            }
         } else {
             launch_gemm_nt(x, ci, d->w[l], ci, d->bias[l], o.act[l], co, b->NP, co, ci, st);
             LAUNCHCHK(); PROF(K_GEMM);
@@ -698,10 +731,16 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
         }
         if (nwm && l > 0 && ci >= 128) {
             // data-gradient GEMM whose epilogue is the backward of block l-1's InstanceNorm+LeakyReLU
-            launch_gemm_clip(dA, co, d->wT[l], co, nullptr, dB, ci, b->B, nwm, b->uniform_tp, ci, co, 2, e->db.rstd[l - 1],
-                             e->db.act[l - 1], st);
             dz_ready = true;
-            LAUNCHCHK(); PROF(K_GEMM_CLIP_BWD);
+            if (get_gemm_clip_config() == 4 && d->wTpk[l] && gemm_clip_x3_supported(nwm, ci, co, co)) {
+                launch_gemm_clip_x3(dA, co, d->wTpk[l], nullptr, dB, ci, b->B, nwm, b->uniform_tp, ci, co, 2,
+                                    e->db.rstd[l - 1], e->db.act[l - 1], st);
+                LAUNCHCHK(); PROF(K_GEMM_X3_BWD);
+            } else {
+                launch_gemm_clip(dA, co, d->wT[l], co, nullptr, dB, ci, b->B, nwm, b->uniform_tp, ci, co, 2, e->db.rstd[l - 1],
+                                 e->db.act[l - 1], st);
+                LAUNCHCHK(); PROF(K_GEMM_CLIP_BWD);
+            }
         } else {
             launch_gemm_nt(dA, co, d->wT[l], co, nullptr, dB, ci, b->NP, ci, co, st);
             dz_ready = false;
@@ -913,6 +952,31 @@ extern "C" int aware_gemm_nt_variant(const float* A, int lda, const float* Bt, i
     if (!A || !Bt || !C || M < 1 || N < 1 || K < 4 || (K & 3) || (lda & 3) || (ldb & 3) || variant < 0 || variant > 16)
         return AWARE_E_BADARG;
     launch_gemm_nt_variant(A, lda, Bt, ldb, bias, C, ldc, M, N, K, variant, (hipStream_t)stream);
+    LAUNCHCHK();
+    return AWARE_OK;
+}
+
+// clip-aligned GEMM alone (tests / roofline): mode 0 = f32 MFMA kernel on Bt, mode 1 = bf16 three-way split kernel on Bpk
+extern "C" size_t aware_x3_packed_bytes(int N, int K) { return (N > 0 && K > 0 && N % 32 == 0) ? x3_packed_bytes(N, K) : 0; }
+extern "C" int aware_x3_pack(const float* host_wt, int N, int K, void* host_out) {
+    if (!host_wt || !host_out || N < 32 || N % 32 || K < 1) return AWARE_E_BADARG;
+    x3_pack(host_wt, N, K, (uint16_t*)host_out);
+    return AWARE_OK;
+}
+extern "C" int aware_gemm_clip(const float* A, int lda, const float* Bt, int ldb, const void* Bpk, const float* bias, float* C,
+                               int ldc, int B, int Tp, int N, int K, int epi, float* rstd_io, const float* act, int mode,
+                               void* stream) {
+    if (!A || !C || B < 1 || Tp < 1 || Tp > 128 || N < 1 || K < 4 || (K & 3) || (lda & 3) || epi < 0 || epi > 2) return AWARE_E_BADARG;
+    if (epi != 0 && !rstd_io) return AWARE_E_BADARG;
+    if (epi == 2 && !act) return AWARE_E_BADARG;
+    const int nwm = (Tp + 31) / 32;
+    if (mode == 1) {
+        if (!Bpk || !gemm_clip_x3_supported(nwm, N, K, lda)) return AWARE_E_BADARG;
+        launch_gemm_clip_x3(A, lda, Bpk, bias, C, ldc, B, nwm, Tp, N, K, epi, rstd_io, act, (hipStream_t)stream);
+    } else {
+        if (!Bt || (ldb & 3)) return AWARE_E_BADARG;
+        launch_gemm_clip(A, lda, Bt, ldb, bias, C, ldc, B, nwm, Tp, N, K, epi, rstd_io, act, (hipStream_t)stream);
+    }
     LAUNCHCHK();
     return AWARE_OK;
 }

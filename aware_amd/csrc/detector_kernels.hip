@@ -531,10 +531,12 @@ static void clip_launch(const float* A, int lda, const float* Bt, int ldb, const
 }
 
 // rows_per_clip = 32 * nwm (1..4).  epi: 0 plain, 1 forward IN+LeakyReLU, 2 backward of IN+LeakyReLU.
-// cfg: 0 = BK 32 / one LDS buffer, 1 = BK 64 / one buffer, 2 = BK 32 / two buffers, 3 = direct-to-LDS
-// loads with two buffers (same numerics in every case)
-static int g_clip_cfg = 0;
+// cfg: 4 (default) = bf16 matrix-pipe kernel with three-way operand split (gemm_x3.hip) wherever the shape allows,
+// else as 0.  f32-MFMA variants (bit-identical among themselves): 0 = BK 32 / one LDS buffer, 1 = BK 64 / one
+// buffer, 2 = BK 32 / two buffers, 3 = direct-to-LDS loads with two buffers
+static int g_clip_cfg = 4;
 void set_gemm_clip_config(int cfg) { g_clip_cfg = cfg; }
+int get_gemm_clip_config() { return g_clip_cfg; }
 void launch_gemm_clip(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc, int B,
                       int nwm, int Tp, int N, int K, int epi, float* rstd_io, const float* act, hipStream_t st) {
 #define CL(M_, E_, K_, D_) clip_launch<M_, 4, E_, K_, D_>(A, lda, Bt, ldb, bias, C, ldc, B, Tp, N, K, rstd_io, act, st)

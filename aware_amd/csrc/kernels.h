@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include <stdint.h>
 #include "common.hpp"
 
 namespace aware {
@@ -78,6 +79,13 @@ int gemm_autotune(const float* A, int lda, const float* Bt, int ldb, float* C, i
 void launch_gemm_clip(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc, int B,
                       int nwm, int Tp, int N, int K, int epi, float* rstd_io, const float* act, hipStream_t st);
 void set_gemm_clip_config(int cfg);
+int get_gemm_clip_config();
+// ---- gemm_x3.hip: the same clip-aligned GEMM on the bf16 matrix pipe, f32-equivalent (3-way operand split) ----
+size_t x3_packed_bytes(int N, int K);
+void x3_pack(const float* Wt, int N, int K, uint16_t* out);      // host: [N][K] f32 -> fragment-ordered bf16 planes
+bool gemm_clip_x3_supported(int nwm, int N, int K, int lda);
+void launch_gemm_clip_x3(const float* A, int lda, const void* Bpk, const float* bias, float* C, int ldc, int B, int nwm,
+                         int Tp, int N, int K, int epi, float* rstd_io, const float* act, hipStream_t st);
 // mel block: InstanceNorm over time, per-clip GlobalStandardize, AvgPool(2,2)
 void launch_mel_norm_fwd(const float* xm, const int* frame_off, const int* pool_off, float* x0, float* stats,
                          float* gstat, float* part, int pstride, int B, int max_frames, hipStream_t st);

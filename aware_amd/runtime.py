@@ -275,6 +275,41 @@ def gemm_nt(a: torch.Tensor, bt: torch.Tensor, bias: torch.Tensor | None = None)
     return c
 
 
+def tune(key: int, value: int) -> None:
+    """Development knob (aware_tune in the header): key 1 selects the kernel of the clip-aligned conv blocks."""
+    check(load_library().aware_tune(int(key), int(value)), "aware_tune")
+
+
+def x3_pack(wt: torch.Tensor) -> torch.Tensor:
+    """[N][K] f32 weights -> the three bf16 planes in MFMA fragment order (device uint8 tensor)."""
+    lib = load_library()
+    w = np.ascontiguousarray(wt.detach().cpu().numpy(), dtype=np.float32)
+    N, K = w.shape
+    nbytes = int(lib.aware_x3_packed_bytes(N, K))
+    if nbytes == 0:
+        raise AwareHipError("aware_x3_pack: N must be a positive multiple of 32")
+    out = np.zeros(nbytes, dtype=np.uint8)
+    check(lib.aware_x3_pack(w.ctypes.data, N, K, out.ctypes.data), "aware_x3_pack")
+    return torch.from_numpy(out).cuda()
+
+
+def gemm_clip(a: torch.Tensor, bt: torch.Tensor, bias, B: int, Tp: int, epi: int = 0, rstd=None, act=None,
+              mode: int = 0, packed=None):
+    """One clip-aligned conv block (tests / roofline).  a: [B*32*ceil(Tp/32), K]; bt: [N, K].
+    Returns (C, rstd)."""
+    lib = load_library()
+    M, K = a.shape
+    N = bt.shape[0]
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    if rstd is None:
+        rstd = torch.zeros((B, N), dtype=torch.float32, device=a.device)
+    if mode == 1 and packed is None:
+        packed = x3_pack(bt)
+    check(lib.aware_gemm_clip(_ptr(a), a.stride(0), _ptr(bt), bt.stride(0), _ptr(packed), _ptr(bias), _ptr(c), N, B, Tp, N, K,
+                              epi, _ptr(rstd), _ptr(act), mode, _stream()), "aware_gemm_clip")
+    return c, rstd
+
+
 # ---------------------------------------------------------------------------------------------
 # ragged signal batches and the attack-stage entry points
 # ---------------------------------------------------------------------------------------------
@@ -387,7 +422,7 @@ def gaussian_noise(x: Ragged, snr_db: float, seeds: Sequence[int]) -> Ragged:
 
 
 KERNEL_KINDS = ["synth", "analysis", "gemm_nt", "mel_norm", "in_lrelu", "readout_tail", "synth_adjoint",
-                "analysis_adjoint_nadam", "misc", "gemm_clip_fwd", "gemm_clip_bwd"]
+                "analysis_adjoint_nadam", "misc", "gemm_clip_fwd", "gemm_clip_bwd", "gemm_x3_fwd", "gemm_x3_bwd"]
 
 
 def embed_profile(sess: EmbedSession, n_iters: int = 3):

@@ -26,6 +26,7 @@ import torch
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: dense f32-input MFMA peak
+MFMA_BF16_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak
 
 
 def detector_flops_per_clip_iter(T):
@@ -67,6 +68,25 @@ def cpu_baseline(seconds_budget=20.0):
     return {"value": 3.0 / full, "unit": "waveform-seconds/sec", "cores": int(torch.get_num_threads()), "kind": "port",
             "sample": f"1 x 3 s clip @16 kHz, {iters} of 400 embed iterations timed ({per_iter*1e3:.1f} ms/iter, "
                       f"extrapolated x400) + 1 detect ({t_det*1e3:.1f} ms); vectorised bounds (no 1.3 s/clip Python loop)"}
+
+
+def pmc_traffic_per_launch(per_gpu):
+    """Mean HBM bytes per gemm_clip launch from the committed PMC passes (profiles/, same kernels and
+    batch; bench.py cannot collect PMC counters itself).  Rows are medians per (kernel, grid); the
+    larger grid of each epilogue kind is launched twice per iteration, the smaller once.
+    Returns (bytes, source) or (None, None) when no profile of this batch size is present."""
+    import csv
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic_pmc.csv")
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        rows = [r for r in csv.reader(l for l in f if not l.startswith("#"))][1:]
+    sel = [(int(r[2]), float(r[3]) + float(r[4])) for r in rows if int(r[0]) == per_gpu and "gemm_clip_kernel" in r[1]]
+    if len(sel) != 4:
+        return None, None
+    big = max(g for g, _ in sel)
+    tot = sum(mb * (2 if g == big else 1) for g, mb in sel)
+    return tot / 6.0 * 1048576.0, "profiles/r01_hbm_traffic_pmc.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 fetch x2 correction)"
 
 
 def log(*a):
@@ -144,13 +164,26 @@ def main():
             d[1] += 1
         rows = sum(t // 2 for t in batch.frames)                 # valid pooled frames of the batch
         ch = embedder.detection_net.channels                     # [128, 512, 1024, 1024, 40]
-        gemm_kinds = [k for k in ("gemm_clip_fwd", "gemm_clip_bwd", "gemm_nt") if k in breakdown]
+        gemm_kinds = [k for k in ("gemm_x3_fwd", "gemm_x3_bwd", "gemm_clip_fwd", "gemm_clip_bwd", "gemm_nt") if k in breakdown]
         all_ms = sum(breakdown[k][0] for k in gemm_kinds)
         all_n = sum(breakdown[k][1] for k in gemm_kinds)
         flops_iter = sum(detector_flops_per_clip_iter(t) for t in batch.frames)
-        if "gemm_clip_fwd" in breakdown:
-            # dominant kernel: the clip-aligned GEMM (3 forward + 3 backward launches per iteration):
-            # conv0..2 forward, and the data gradients of conv3..1 (whose epilogues differentiate IN+LeakyReLU)
+        peak, peak_note = MFMA_F32_PEAK_TF, "dense f32-input MFMA peak"
+        if "gemm_x3_fwd" in breakdown:
+            # dominant kernel: the clip-aligned conv block on the bf16 matrix pipe (gemm_x3.hip), 5 launches per
+            # iteration: conv0..2 forward (K = 128, 512, 1024) and the data gradients of conv2, conv1 (K = 1024);
+            # the K = 40 data gradient of conv3 stays on the f32-MFMA kernel and is not counted here
+            fl = 2.0 * rows * (ch[0] * ch[1] + ch[1] * ch[2] + ch[2] * ch[3]) + 2.0 * rows * (ch[3] * ch[2] + ch[2] * ch[1])
+            ms = breakdown["gemm_x3_fwd"][0] + breakdown["gemm_x3_bwd"][0]
+            nl = breakdown["gemm_x3_fwd"][1] + breakdown["gemm_x3_bwd"][1]
+            name = "aware::gemm_clip_x3_kernel<3,EPI> (EPI=1 forward x3, EPI=2 backward x2 per iteration)"
+            per_kernel = {"gemm_clip_x3_kernel<3,1>": round(breakdown["gemm_x3_fwd"][0] * 1e3 / breakdown["gemm_x3_fwd"][1], 2),
+                          "gemm_clip_x3_kernel<3,2>": round(breakdown["gemm_x3_bwd"][0] * 1e3 / breakdown["gemm_x3_bwd"][1], 2)}
+            peak = MFMA_BF16_PEAK_TF / 6.0
+            peak_note = ("f32-equivalent peak of this kernel: dense bf16 MFMA peak (2.5 PFLOP/s) / 6 bf16 partial products per "
+                         "f32 multiply-add")
+        elif "gemm_clip_fwd" in breakdown:
+            # f32-MFMA clip-aligned GEMM (aware_tune(1, 0)): 3 forward + 3 backward launches per iteration
             fl = 2.0 * rows * (ch[0] * ch[1] + ch[1] * ch[2] + ch[2] * ch[3]) + 2.0 * rows * (ch[4] * ch[3] + ch[3] * ch[2] + ch[2] * ch[1])
             ms = breakdown["gemm_clip_fwd"][0] + breakdown["gemm_clip_bwd"][0]
             nl = breakdown["gemm_clip_fwd"][1] + breakdown["gemm_clip_bwd"][1]
@@ -164,8 +197,10 @@ def main():
         achieved = fl * n_it / (ms * 1e-3) / 1e12
         dsp_ms = sum(breakdown[k][0] for k in ("synth", "analysis", "synth_adjoint", "analysis_adjoint_nadam"))
         dsp_bytes = sum(dsp_bytes_per_clip_iter(t) for t in batch.frames) * n_it
-        roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TF,
-                "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TF, 4), "traffic": None,
+        roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": round(peak, 1),
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None, "peak_note": peak_note,
+                "frac_of_f32_mfma_peak": round(achieved / MFMA_F32_PEAK_TF, 4),
+                "traffic_unit": "bytes/launch", "traffic_source": None,
                 "avg_launch_us": round(ms * 1e3 / nl, 2), "launches_timed": nl,
                 "algorithmic_flops_per_launch": fl * n_it / nl, "avg_launch_us_by_kernel": per_kernel,
                 "all_detector_gemms": {"achieved": round(flops_iter * n_it / (all_ms * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
@@ -175,6 +210,15 @@ def main():
                             "unit": "GB/s", "frac": round(dsp_bytes / (dsp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                             "avg_launch_us": round(dsp_ms * 1e3 / (4 * n_it), 2)}}
 
+        if "gemm_x3_fwd" not in breakdown and "gemm_clip_fwd" in breakdown and len(set(batch.frames)) == 1:
+            tb, src = pmc_traffic_per_launch(len(batch.frames))
+            if tb is not None:
+                roof["traffic"], roof["traffic_source"] = round(tb), src
+                # operands of one launch: A rows + output rows + weights
+                alg = 4.0 * (rows * (ch[0] + ch[1]) + rows * (ch[1] + ch[2]) + rows * (ch[2] + ch[3])
+                             + rows * (ch[4] + ch[3]) + rows * (ch[3] + ch[2]) + rows * (ch[2] + ch[1])
+                             + 2 * (ch[0] * ch[1] + ch[1] * ch[2] + ch[2] * ch[3]) + ch[3] * ch[4])
+                roof["algorithmic_bytes_per_launch"] = round(alg / 6)
     if world > 1:
         import torch.distributed as dist
         parallel.barrier()

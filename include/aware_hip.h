@@ -47,9 +47,11 @@ typedef struct aware_embed aware_embed;
 
 int aware_version(void);
 const char* aware_last_hip_error(void);
-/* development knob, not part of the drop-in surface: key 1 = K-tile / LDS buffering of the
- * clip-aligned GEMM (0: BK 32 x1 [default, fastest measured], 1: BK 64 x1, 2: BK 32 x2, 3: direct-to-LDS
- * loads x2); every setting gives identical results */
+/* development knob, not part of the drop-in surface: key 1 = kernel of the clip-aligned conv blocks.
+ * 4 [default]: bf16 matrix pipe, operands split exactly into three bf16 terms, six partial products per
+ * multiply-add, f32 accumulation (f32-equivalent accuracy; csrc/gemm_x3.hip) for K % 64 == 0, N % 128 == 0,
+ * f32 MFMA otherwise.  0..3: f32 MFMA everywhere (0: BK 32 x1, 1: BK 64 x1, 2: BK 32 x2, 3: direct-to-LDS
+ * loads x2; identical results among 0..3). */
 int aware_tune(int key, int value);
 
 /* ---- plan: FFT twiddles, window, band ------------------------------------------------
@@ -194,6 +196,20 @@ int aware_gemm_nt(const float* A, int lda, const float* Bt, int ldb, const float
  * configurations produce bit-identical results) */
 int aware_gemm_nt_variant(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc,
                           int M, int N, int K, int variant, void* stream);
+
+/* ---- the clip-aligned conv block alone (tests / roofline) ----------------------------------------------
+ * One Conv1dBlock of the detector (detection/modules/conv1d.py:38-42) on a uniform batch: clip b owns rows
+ * [b*32*ceil(Tp/32), +Tp) of A and C (the rest of each 32-row group is padding, written as zero).
+ *   epi 0: C = A*Bt^T + bias          epi 1: C = LeakyReLU_0.2(InstanceNorm_t(A*Bt^T + bias)), rstd_io[b][n] written
+ *   epi 2: A is dL/d(output of the previous block), act that output; C = dL/d(its pre-norm conv output)
+ * mode 0 runs the f32-MFMA kernel on Bt [N][K]; mode 1 the bf16 matrix-pipe kernel on Bpk, the same matrix split
+ * exactly into three bf16 planes and re-ordered by aware_x3_pack (host buffers; aware_x3_packed_bytes bytes);
+ * six partial products per multiply-add, f32 accumulation: f32-equivalent results (N % 128 == 0, K % 64 == 0). */
+size_t aware_x3_packed_bytes(int N, int K);
+int aware_x3_pack(const float* host_wt, int N, int K, void* host_out);
+int aware_gemm_clip(const float* A, int lda, const float* Bt, int ldb, const void* Bpk, const float* bias, float* C,
+                    int ldc, int B, int Tp, int N, int K, int epi, float* rstd_io, const float* act, int mode,
+                    void* stream);
 
 #ifdef __cplusplus
 }

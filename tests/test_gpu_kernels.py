@@ -59,6 +59,76 @@ def test_gemm_nt(rt, M, N, K):
     assert (out2.double() - (ref - bias.double())).abs().max().item() < 2e-6 * scale * max(1.0, K / 256)
 
 
+def _block_reference(a, w, bias, act, rstd, B, RP, Tp, epi):
+    """fp64 restatement of one Conv1dBlock (detection/modules/conv1d.py:38-42) / of its backward."""
+    N = w.shape[0]
+    z = (a.double() @ w.double().T).view(B, RP, N)[:, :Tp]
+    if epi == 0:
+        return z + bias.double()
+    if epi == 1:
+        z = z + bias.double()
+        u = (z - z.mean(1, keepdim=True)) / torch.sqrt(z.var(1, unbiased=False, keepdim=True) + 1e-5)
+        return torch.where(u > 0, u, 0.2 * u)
+    av = act.double().view(B, RP, N)[:, :Tp]
+    u = torch.where(av > 0, av, av * 5.0)
+    du = z * torch.where(av > 0, 1.0, 0.2)
+    return rstd.double()[:, None, :] * (du - du.mean(1, keepdim=True) - u * (du * u).mean(1, keepdim=True))
+
+
+@pytest.mark.parametrize("B,Tp,N,K,epi", [(5, 94, 512, 128, 1), (3, 94, 1024, 512, 1), (4, 94, 1024, 1024, 2), (2, 31, 128, 64, 0),
+                                          (3, 64, 256, 192, 1), (2, 128, 128, 320, 2), (9, 50, 384, 128, 0)])
+def test_gemm_clip_x3(rt, B, Tp, N, K, epi):
+    """The bf16 three-way-split conv block against fp64, beside the f32-MFMA kernel on the same inputs:
+    its error must be at the level of a k-ordered f32 fma chain (f32-equivalent), for every epilogue."""
+    RP = 32 * ((Tp + 31) // 32)
+    g = torch.Generator().manual_seed(B * 1000 + Tp + N + K + epi)
+    a = torch.randn(B * RP, K, generator=g)
+    a.view(B, RP, K)[:, Tp:] = 0
+    # wide dynamic range in the weights: exercises all three bf16 planes
+    w = torch.randn(N, K, generator=g) * torch.exp2(torch.randint(-6, 4, (N, 1), generator=g).float()) / K ** 0.5
+    bias = torch.randn(N, generator=g) * 0.1 if epi != 2 else None
+    act = torch.randn(B * RP, N, generator=g) if epi == 2 else None
+    rstd = torch.rand(B, N, generator=g) + 0.5 if epi == 2 else None
+    ref = _block_reference(a, w, bias, act, rstd, B, RP, Tp, epi)
+    outs = []
+    for mode in (0, 1):
+        c, rs = rt.gemm_clip(a.cuda(), w.cuda(), None if bias is None else bias.cuda(), B, Tp, epi,
+                             None if rstd is None else rstd.cuda(), None if act is None else act.cuda(), mode)
+        c = c.cpu().view(B, RP, N)
+        assert c[:, Tp:].abs().max().item() == 0.0 if RP > Tp else True       # padding rows are written as zero
+        outs.append(c[:, :Tp].double())
+        if epi == 1:
+            z = (a.double() @ w.double().T).view(B, RP, N)[:, :Tp] + bias.double()
+            ref_rs = 1.0 / torch.sqrt(z.var(1, unbiased=False) + 1e-5)
+            assert ((rs.cpu().double() - ref_rs).abs() / ref_rs).max().item() < 2e-5
+    # per-column scale: the weights span 2^10
+    scale = ref.abs().amax(dim=(0, 1), keepdim=True).clamp_min(1e-30)
+    e32 = ((outs[0] - ref).abs() / scale).max().item()
+    ex3 = ((outs[1] - ref).abs() / scale).max().item()
+    print(f"max column-relative error: f32 MFMA {e32:.2e}, bf16x3 {ex3:.2e}")
+    tol = 4e-6 * max(1.0, K / 256)
+    assert e32 < tol and ex3 < tol, (e32, ex3)
+    assert ex3 < 2.0 * e32 + 2e-7, (e32, ex3)          # never meaningfully worse than the f32 pipe
+
+
+def test_x3_split_is_exact(rt):
+    """The three bf16 planes of aware_x3_pack sum back to the f32 weights bit for bit."""
+    g = torch.Generator().manual_seed(7)
+    w = (torch.randn(64, 48, generator=g) * torch.exp2(torch.randint(-20, 20, (64, 48), generator=g).float())).contiguous()
+    pk = rt.x3_pack(w).cpu().numpy().view(np.uint16)
+    KS = 3
+    pk = pk.reshape(2, KS, 3, 64, 8)                      # [n tile][k16 step][plane][lane][j]
+    planes = (pk.astype(np.uint32) << 16).view(np.float32)
+    back = np.zeros((64, 48), dtype=np.float32)
+    for nt in range(2):
+        for ks in range(KS):
+            for lane in range(64):
+                n, k0 = nt * 32 + (lane & 31), ks * 16 + 8 * (lane >> 5)
+                p = planes[nt, ks, :, lane, :]
+                back[n, k0:k0 + 8] = (p[0] + p[1]) + p[2]
+    np.testing.assert_array_equal(back, w.numpy())
+
+
 @pytest.mark.parametrize("lengths", [[48000], [16000, 48000, 20000], [48000] * 5, [16000 + 37, 513 + 256 * 14, 160000]])
 def test_stft_istft_vs_oracle(rt, plan, O, lengths):
     """BASELINE config 2: STFT parity <= 1e-5 relative, round trip <= 2e-6 abs (unit-peak audio)."""
@@ -225,3 +295,29 @@ def test_embed_full_1s_bits_exact(rt, plan, det, O):
     lo, hi = sess.bounds
     bc = sess.best_coef
     assert bool(((bc >= lo) & (bc <= hi)).all())
+
+
+def test_first_iteration_x3_vs_f32_pipe(rt, plan, det, O):
+    """Whole first loop body with the conv blocks on the bf16x3 kernel (default) and on the f32-MFMA kernel:
+    loss, prediction and dL/dcoef agree to f32 rounding."""
+    lengths = [48000] * 3
+    pairs = [make_clip(40 + i, n) for i, n in enumerate(lengths)]
+    wm = np.stack([O.bits_to_bipolar(p[1]) for p in pairs]).astype(np.float32)
+    batch = rt.Batch(lengths)
+    res = []
+    try:
+        for cfg in (4, 0):
+            rt.tune(1, cfg)
+            sess = rt.EmbedSession(plan, det, batch, use_graph=False)
+            sess.begin(batch.pack([p[0] for p in pairs]), torch.from_numpy(wm).cuda())
+            g = sess.gradient()
+            torch.cuda.synchronize()
+            res.append((g.cpu().double(), sess.loss.cpu().numpy().copy(), sess.pred.cpu().numpy().copy()))
+    finally:
+        rt.tune(1, 4)
+    (g4, l4, p4), (g0, l0, p0) = res
+    assert np.max(np.abs(l4 - l0)) < 2e-6
+    assert np.max(np.abs(p4 - p0)) < 2e-6
+    rel = ((g4 - g0).norm() / g0.norm()).item()
+    print("relative L2 difference of the gradients, bf16x3 vs f32 MFMA:", rel)
+    assert rel < 2e-5, rel
