@@ -81,6 +81,8 @@ struct aware_detector {
     // shape is not served by that kernel
     void* wpk[8] = {nullptr};
     void* wTpk[8] = {nullptr};
+    void* melTpk = nullptr;
+    void* melBpk = nullptr;
     void* pkmem = nullptr;
     float* bias[8] = {nullptr};
 };
@@ -366,7 +368,11 @@ extern "C" int aware_detector_create(aware_detector** out, const aware_plan* pla
             if (co % 128 == 0 && ci % 64 == 0) { o_pk[l] = pk_total; pk_total += x3_packed_bytes(co, ci); }
             if (ci % 128 == 0 && co % 64 == 0) { o_pkT[l] = pk_total; pk_total += x3_packed_bytes(ci, co); }
         }
+        const size_t o_mT = pk_total; pk_total += x3_packed_bytes(n_mels, kFS);
+        const size_t o_mB = pk_total; pk_total += x3_packed_bytes(kFS, n_mels);
         std::vector<uint16_t> hp(pk_total / 2 + 8, 0);
+        x3_pack(h.data() + o_melT, n_mels, kFS, hp.data() + o_mT / 2);
+        x3_pack(h.data() + o_melB, kFS, n_mels, hp.data() + o_mB / 2);
         for (int l = 0; l < n_layers; ++l) {
             const int ci = channels[l], co = channels[l + 1];
             if (o_pk[l] != (size_t)-1) x3_pack(h.data() + o_w[l], co, ci, hp.data() + o_pk[l] / 2);
@@ -374,6 +380,8 @@ extern "C" int aware_detector_create(aware_detector** out, const aware_plan* pla
         }
         HIPCHK(hipMalloc(&d->pkmem, pk_total + 16));
         HIPCHK(hipMemcpy(d->pkmem, hp.data(), pk_total, hipMemcpyHostToDevice));
+        d->melTpk = (char*)d->pkmem + o_mT;
+        d->melBpk = (char*)d->pkmem + o_mB;
         for (int l = 0; l < n_layers; ++l) {
             if (o_pk[l] != (size_t)-1) d->wpk[l] = (char*)d->pkmem + o_pk[l];
             if (o_pkT[l] != (size_t)-1) d->wTpk[l] = (char*)d->pkmem + o_pkT[l];
@@ -387,6 +395,16 @@ extern "C" void aware_detector_destroy(aware_detector* d) {
     if (d->mem) (void)hipFree(d->mem);
     if (d->pkmem) (void)hipFree(d->pkmem);
     delete d;
+}
+
+// Plain GEMM C[M][N] = A[M][K] * Bt^T on the bf16x3 kernel when its packed operand exists and the shape fits
+// (32-row blocks play the role of clips; plain epilogue), else on the f32-MFMA kernel.
+static void gemm_plain(const float* A, int lda, const float* Bt, int ldb, const void* Bpk, const float* bias, float* C,
+                       int ldc, int M, int N, int K, hipStream_t st) {
+    if (get_gemm_clip_config() == 4 && Bpk && M % 32 == 0 && gemm_clip_x3_supported(1, N, K, lda))
+        launch_gemm_clip_x3(A, lda, Bpk, bias, C, ldc, M / 32, 1, 32, N, K, 0, nullptr, nullptr, st);
+    else
+        launch_gemm_nt(A, lda, Bt, ldb, bias, C, ldc, M, N, K, st);
 }
 
 // detector activations carved from a workspace
@@ -435,7 +453,7 @@ static int clip_tile_groups(const aware_batch* b) {
 
 // forward through the network; mag [NF][256] -> act[last], pred
 static int det_forward(const aware_detector* d, const aware_batch* b, const float* mag, DetBufs& o, hipStream_t st) {
-    launch_gemm_nt(mag, kFS, d->melT, kFS, nullptr, o.xm, 128, b->NF, 128, kFS, st);
+    gemm_plain(mag, kFS, d->melT, kFS, d->melTpk, nullptr, o.xm, 128, b->NF, 128, kFS, st);
     LAUNCHCHK(); PROF(K_GEMM);
     launch_mel_norm_fwd(o.xm, b->d_frame_off, b->d_pool_off, o.x0, o.mstats, o.gstat, o.mpart, o.mstride, b->B,
                         b->max_frames, st);
@@ -742,7 +760,7 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
                 LAUNCHCHK(); PROF(K_GEMM_CLIP_BWD);
             }
         } else {
-            launch_gemm_nt(dA, co, d->wT[l], co, nullptr, dB, ci, b->NP, ci, co, st);
+            gemm_plain(dA, co, d->wT[l], co, d->wTpk[l], nullptr, dB, ci, b->NP, ci, co, st);
             dz_ready = false;
             LAUNCHCHK(); PROF(K_GEMM);
         }
@@ -751,7 +769,7 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
     launch_mel_norm_bwd(dA, e->db.xm, b->d_frame_off, b->d_pool_off, e->db.mstats, e->db.gstat, e->db.mpart,
                         e->db.mstride, b->B, b->max_frames, st);
     LAUNCHCHK(); PROF(K_MELNORM);
-    launch_gemm_nt(e->db.xm, 128, d->melB, 128, nullptr, e->gmag, kFS, b->NF, kFS, 128, st);
+    gemm_plain(e->db.xm, 128, d->melB, 128, d->melBpk, nullptr, e->gmag, kFS, b->NF, kFS, 128, st);
     LAUNCHCHK(); PROF(K_GEMM);
     // backward through |.|, STFT, reflect padding
     SynthLaunch SA;
@@ -957,9 +975,9 @@ extern "C" int aware_gemm_nt_variant(const float* A, int lda, const float* Bt, i
 }
 
 // clip-aligned GEMM alone (tests / roofline): mode 0 = f32 MFMA kernel on Bt, mode 1 = bf16 three-way split kernel on Bpk
-extern "C" size_t aware_x3_packed_bytes(int N, int K) { return (N > 0 && K > 0 && N % 32 == 0) ? x3_packed_bytes(N, K) : 0; }
+extern "C" size_t aware_x3_packed_bytes(int N, int K) { return (N > 0 && K > 0 && N % 16 == 0) ? x3_packed_bytes(N, K) : 0; }
 extern "C" int aware_x3_pack(const float* host_wt, int N, int K, void* host_out) {
-    if (!host_wt || !host_out || N < 32 || N % 32 || K < 1) return AWARE_E_BADARG;
+    if (!host_wt || !host_out || N < 16 || N % 16 || K < 1) return AWARE_E_BADARG;
     x3_pack(host_wt, N, K, (uint16_t*)host_out);
     return AWARE_OK;
 }

@@ -287,7 +287,7 @@ def x3_pack(wt: torch.Tensor) -> torch.Tensor:
     N, K = w.shape
     nbytes = int(lib.aware_x3_packed_bytes(N, K))
     if nbytes == 0:
-        raise AwareHipError("aware_x3_pack: N must be a positive multiple of 32")
+        raise AwareHipError("aware_x3_pack: N must be a positive multiple of 16")
     out = np.zeros(nbytes, dtype=np.uint8)
     check(lib.aware_x3_pack(w.ctypes.data, N, K, out.ctypes.data), "aware_x3_pack")
     return torch.from_numpy(out).cuda()

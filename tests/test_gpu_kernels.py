@@ -116,16 +116,18 @@ def test_x3_split_is_exact(rt):
     g = torch.Generator().manual_seed(7)
     w = (torch.randn(64, 48, generator=g) * torch.exp2(torch.randint(-20, 20, (64, 48), generator=g).float())).contiguous()
     pk = rt.x3_pack(w).cpu().numpy().view(np.uint16)
-    KS = 3
-    pk = pk.reshape(2, KS, 3, 64, 8)                      # [n tile][k16 step][plane][lane][j]
+    KS = 2                                                # K = 48 is padded to two k32 steps
+    pk = pk.reshape(4, KS, 3, 64, 8)                      # [16-column tile][k32 step][plane][lane][j]
     planes = (pk.astype(np.uint32) << 16).view(np.float32)
-    back = np.zeros((64, 48), dtype=np.float32)
-    for nt in range(2):
+    back = np.zeros((64, 64), dtype=np.float32)
+    for nt in range(4):
         for ks in range(KS):
             for lane in range(64):
-                n, k0 = nt * 32 + (lane & 31), ks * 16 + 8 * (lane >> 5)
+                n, k0 = nt * 16 + (lane & 15), ks * 32 + 8 * (lane >> 4)
                 p = planes[nt, ks, :, lane, :]
                 back[n, k0:k0 + 8] = (p[0] + p[1]) + p[2]
+    assert not back[:, 48:].any()
+    back = back[:, :48]
     np.testing.assert_array_equal(back, w.numpy())
 
 

@@ -34,12 +34,12 @@ for (N, K, epi) in [(512, 128, 1), (1024, 512, 1), (1024, 1024, 1), (1024, 40, 2
     ad, wd = a.cuda(), w.cuda()
     bd = bias.cuda() if bias is not None else None
     actd = act.cuda() if act is not None else None
-    pk = rt.x3_pack(w)
+    pk = {0: None, 1: rt.x3_pack(w)}
     outs = []
-    modes = (0, 1) if K % 64 == 0 else (0, 0)
+    modes = (0, 1) if K % 64 == 0 else (0,)
     for mode in modes:
         r = rstd.cuda() if rstd is not None else None
-        c, rs = rt.gemm_clip(ad, wd, bd, B, Tp, epi, r, actd, mode, pk)
+        c, rs = rt.gemm_clip(ad, wd, bd, B, Tp, epi, r, actd, mode, pk[mode])
         outs.append(c.cpu().double())
     # fp64 reference
     z = a.double() @ w.double().T
@@ -60,7 +60,7 @@ for (N, K, epi) in [(512, 128, 1), (1024, 512, 1), (1024, 1024, 1), (1024, 40, 2
     t = []
     for mode in modes:
         r = rstd.cuda() if rstd is not None else torch.zeros(B, N, device="cuda")
-        t.append(bench(lambda: rt.gemm_clip(ad, wd, bd, B, Tp, epi, r, actd, mode, pk)))
+        t.append(bench(lambda: rt.gemm_clip(ad, wd, bd, B, Tp, epi, r, actd, mode, pk[mode])))
     fl = 2.0 * B * Tp * N * K
-    print(f"N={N:5d} K={K:5d} epi={epi}  relerr f32 {errs[0]:.2e}  x3 {errs[1]:.2e}  pad {pad}  "
-          f"time f32 {t[0]:7.1f} us ({fl / t[0] / 1e6:6.1f} TF)  x3 {t[1]:7.1f} us ({fl / t[1] / 1e6:6.1f} TF)", flush=True)
+    print(f"N={N:5d} K={K:5d} epi={epi}  relerr " + " ".join(f"{e:.2e}" for e in errs) + f"  pad {max(pad)}  time us (TF): "
+          + "  ".join(f"m{m} {tt:6.1f} ({fl / tt / 1e6:5.1f})" for m, tt in zip(modes, t)), flush=True)
