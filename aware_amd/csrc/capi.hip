@@ -83,6 +83,8 @@ struct aware_detector {
     void* wTpk[8] = {nullptr};
     void* melTpk = nullptr;
     void* melBpk = nullptr;
+    void* lastpk = nullptr;    // last conv, rows zero-padded to a multiple of 16 (read-out kernel)
+    void* lastTpk = nullptr;   // its transpose [Cin][64], k zero-padded to 64
     void* pkmem = nullptr;
     float* bias[8] = {nullptr};
 };
@@ -370,7 +372,26 @@ extern "C" int aware_detector_create(aware_detector** out, const aware_plan* pla
         }
         const size_t o_mT = pk_total; pk_total += x3_packed_bytes(n_mels, kFS);
         const size_t o_mB = pk_total; pk_total += x3_packed_bytes(kFS, n_mels);
+        // read-out kernel operands (last conv block, C <= 64 channels)
+        const int cil = channels[n_layers - 1], col = channels[n_layers], colp = 16 * ((col + 15) / 16);
+        const bool ro = n_layers >= 2 && readout_x3_supported(1, cil, col);
+        size_t o_lp = 0, o_lT = 0;
+        if (ro) {
+            o_lp = pk_total; pk_total += x3_packed_bytes(colp, cil);
+            o_lT = pk_total; pk_total += x3_packed_bytes(cil, 64);
+        }
         std::vector<uint16_t> hp(pk_total / 2 + 8, 0);
+        if (ro) {
+            std::vector<float> wp((size_t)colp * cil, 0.f), wt((size_t)cil * 64, 0.f);
+            for (int r = 0; r < col; ++r)
+                for (int c = 0; c < cil; ++c) {
+                    const float v = weights[n_layers - 1][(size_t)r * cil + c];
+                    wp[(size_t)r * cil + c] = v;
+                    wt[(size_t)c * 64 + r] = v;
+                }
+            x3_pack(wp.data(), colp, cil, hp.data() + o_lp / 2);
+            x3_pack(wt.data(), cil, 64, hp.data() + o_lT / 2);
+        }
         x3_pack(h.data() + o_melT, n_mels, kFS, hp.data() + o_mT / 2);
         x3_pack(h.data() + o_melB, kFS, n_mels, hp.data() + o_mB / 2);
         for (int l = 0; l < n_layers; ++l) {
@@ -380,6 +401,7 @@ extern "C" int aware_detector_create(aware_detector** out, const aware_plan* pla
         }
         HIPCHK(hipMalloc(&d->pkmem, pk_total + 16));
         HIPCHK(hipMemcpy(d->pkmem, hp.data(), pk_total, hipMemcpyHostToDevice));
+        if (ro) { d->lastpk = (char*)d->pkmem + o_lp; d->lastTpk = (char*)d->pkmem + o_lT; }
         d->melTpk = (char*)d->pkmem + o_mT;
         d->melBpk = (char*)d->pkmem + o_mB;
         for (int l = 0; l < n_layers; ++l) {
@@ -452,7 +474,8 @@ static int clip_tile_groups(const aware_batch* b) {
 }
 
 // forward through the network; mag [NF][256] -> act[last], pred
-static int det_forward(const aware_detector* d, const aware_batch* b, const float* mag, DetBufs& o, hipStream_t st) {
+static int det_forward(const aware_detector* d, const aware_batch* b, const float* mag, DetBufs& o, hipStream_t st,
+                       bool skip_last = false) {
     gemm_plain(mag, kFS, d->melT, kFS, d->melTpk, nullptr, o.xm, 128, b->NF, 128, kFS, st);
     LAUNCHCHK(); PROF(K_GEMM);
     launch_mel_norm_fwd(o.xm, b->d_frame_off, b->d_pool_off, o.x0, o.mstats, o.gstat, o.mpart, o.mstride, b->B,
@@ -461,7 +484,7 @@ static int det_forward(const aware_detector* d, const aware_batch* b, const floa
     const float* x = o.x0;
     const int nwm = clip_tile_groups(b);
     o.tail = 0;
-    for (int l = 0; l < d->n_layers; ++l) {
+    for (int l = 0; l < d->n_layers - (skip_last ? 1 : 0); ++l) {
         const int ci = d->ch[l], co = d->ch[l + 1];
         if (l == d->n_layers - 1 && co <= 64 && b->max_frames / 2 <= 320) {
             // skinny last conv: split-K partial slabs, summed inside the fused tail kernel
@@ -480,7 +503,7 @@ static int det_forward(const aware_detector* d, const aware_batch* b, const floa
                 LAUNCHCHK(); PROF(K_GEMM_CLIP_FWD);
             }
         } else {
-            launch_gemm_nt(x, ci, d->w[l], ci, d->bias[l], o.act[l], co, b->NP, co, ci, st);
+            gemm_plain(x, ci, d->w[l], ci, d->wpk[l], d->bias[l], o.act[l], co, b->NP, co, ci, st);
             LAUNCHCHK(); PROF(K_GEMM);
             launch_in_lrelu_fwd(o.act[l], b->d_frame_off, b->d_pool_off, o.rstd[l], co, b->B, b->max_frames / 2, st);
             LAUNCHCHK(); PROF(K_INLRELU);
@@ -722,14 +745,26 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
     launch_analysis(L, st);
     LAUNCHCHK(); PROF(K_ANALYSIS);
     // :107 detector forward
-    int rc = det_forward(d, b, e->mag, e->db, st);
+    const int nwm = clip_tile_groups(b);
+    // one kernel for the last conv block, the BRH head, the loss, their backward and the data gradient of the last
+    // conv (uniform batches, bf16x3 configuration); otherwise split-K GEMM + tail kernel + data-gradient GEMM
+    const bool fused_readout = get_gemm_clip_config() == 4 && nwm && nl >= 2 && d->lastpk && e->target &&
+                               readout_x3_supported(nwm, d->ch[nl - 1], d->ch[nl]) && d->ch[nl - 1] >= 128;
+    int rc = det_forward(d, b, e->mag, e->db, st, fused_readout);
     if (rc) return rc;
     // :109 loss, :120-122 best tracking, gradient seed
     float* dA = e->d1;
     float* dB = e->d2;
     int* step_ptr = do_step ? e->step : nullptr;        // the read-out kernel advances the step counter
     bool dz_ready = false;      // dA already holds dL/dZ of layer l (fused into the producing kernel)
-    if (e->db.tail) {
+    int l_top = nl - 1;         // first layer the backward loop below still has to differentiate
+    if (fused_readout) {
+        launch_readout_x3(e->db.act[nl - 2], d->ch[nl - 1], d->lastpk, d->bias[nl - 1], d->lastTpk, e->db.rstd[nl - 2],
+                          e->target, e->db.pred, e->loss, e->best_loss, e->improved, step_ptr, dA, b->B, nwm,
+                          b->uniform_tp, d->ch[nl], d->nbits, e->cfg.loss, st);
+        dz_ready = true;
+        l_top = nl - 2;
+    } else if (e->db.tail) {
         launch_tail(e->db.zpart, kTailSplit, (size_t)b->NP * d->ch[nl], d->bias[nl - 1], b->d_frame_off, b->d_pool_off,
                     e->target, e->db.pred, e->loss, e->best_loss, e->improved, dA, step_ptr, e->cfg.loss, d->nbits, b->B,
                     b->max_frames / 2, st);
@@ -740,8 +775,7 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
     }
     LAUNCHCHK(); PROF(K_HEAD);
     // :111 backward through the detector (data gradients only; weights are frozen :76-77)
-    const int nwm = clip_tile_groups(b);
-    for (int l = nl - 1; l >= 0; --l) {
+    for (int l = l_top; l >= 0; --l) {
         const int ci = d->ch[l], co = d->ch[l + 1];
         if (!dz_ready) {
             launch_in_lrelu_bwd(dA, e->db.act[l], b->d_frame_off, b->d_pool_off, e->db.rstd[l], co, b->B, b->max_frames / 2, st);

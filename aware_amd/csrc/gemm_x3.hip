@@ -28,6 +28,7 @@
 #include <stdint.h>
 #include <string.h>
 #include "kernels.h"
+#include "common.hpp"
 
 #ifndef X3_ABLATE
 #define X3_ABLATE 0
@@ -324,6 +325,369 @@ void launch_gemm_clip_x3(const float* A, int lda, const void* Bpk, const float* 
 
 bool gemm_clip_x3_supported(int nwm, int N, int K, int lda) {
     return nwm >= 1 && nwm <= 4 && N % 128 == 0 && K % 64 == 0 && lda % 4 == 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Read-out block of the embed loop in ONE kernel (uniform batches): last Conv1dBlock (C <= 64 channels)
+// -> InstanceNorm -> LeakyReLU -> BRH head -> loss -> backward of all of it -> data gradient of the last
+// conv -> backward of the previous block's InstanceNorm + LeakyReLU.  Replaces three launches (split-K
+// GEMM, tail kernel, clip-aligned data-gradient GEMM) whose work is tiny and latency-bound.
+//   reference: detection/multibit_detector_net.py:58-70,133-140 (last block + BRH), modules/BRH.py:16-27,
+//              embedding/losses.py, embedding/multibit_embedder.py:109-122 (loss, best tracking)
+// Grid: G workgroups per clip (G = Cin/256); each recomputes the clip's [Tp x C] forward (K = Cin, 8 waves =
+// one 16-row tile per wave, A split in registers straight from global memory, no LDS), then owns 256 of the
+// Cin columns of the data gradient.  Only workgroup g = 0 of a clip writes pred / loss / best tracking.
+// ---------------------------------------------------------------------------------------------------
+#ifdef RO_STAMP
+__device__ unsigned long long g_ro_stamps[16];
+#define STAMP(i) do { if (blockIdx.x == 17 && threadIdx.x == 0) g_ro_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int aware_debug_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ro_stamps), sizeof(g_ro_stamps)); }
+#else
+#define STAMP(i)
+#endif
+template <int RG, int NC>
+__global__ __launch_bounds__(512) void readout_x3_kernel(const float* __restrict__ hin, int ci,
+                                                          const u32x4* __restrict__ Wpk, const float* __restrict__ bias,
+                                                          const u32x4* __restrict__ WTpk, const float* __restrict__ rstd_prev,
+                                                          const float* __restrict__ target, float* __restrict__ pred,
+                                                          float* __restrict__ loss_out, float* __restrict__ best_loss,
+                                                          int* __restrict__ improved, int* __restrict__ step,
+                                                          float* __restrict__ dZ, int Tp, int C, int nbits, int loss_kind,
+                                                          int G, int ntiles) {
+    constexpr int MT = 2 * RG;
+    constexpr int MH = RG;
+    constexpr int FRAG = 1024;
+    constexpr int KSC = 2;                           // K32 steps of the data-gradient GEMM (C <= 64)
+    constexpr int IMG = KSC * 3 * MT * FRAG;         // dZ_last as A fragments of the data-gradient GEMM
+    constexpr int PART = 8 * MH * NC * FRAG;         // split-K partial tiles of half the clip's rows, all 8 waves
+    __shared__ __attribute__((aligned(16))) unsigned char smem[IMG > PART ? IMG : PART];
+    unsigned char* const img = smem;
+    __shared__ float red[6][8][64];
+    __shared__ float mean_s[64], dm[64];
+
+    int id = blockIdx.x;
+    if ((ntiles & 7) == 0) id = (id & 7) * (ntiles >> 3) + (id >> 3);
+    const int clip = id / G, g = id % G;
+    const int bm = clip * 32 * RG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kg = lane >> 4;
+    const float invT = 1.0f / (float)Tp;
+
+    STAMP(0);
+    // ---- phase 1: z = h * W^T.  K is split over the 8 waves (K32 steps wave, wave+8, ...); every wave covers all
+    //      rows of the clip with A split in registers straight from global memory (no LDS staging) ----
+    f32x4 zp[MT][NC];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NC; ++n) zp[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int KS2 = ci >> 5;
+    {
+        const int nsteps = KS2 >> 3;                   // Cin % 512 == 0: an even number of steps per wave
+        const float* abase = hin + (size_t)(bm + r16) * ci + 8 * kg;
+        const u32x4* bp = Wpk + lane;
+        float4 an[MT][2];
+        u32x4 bb[2][NC][3];
+        auto loadA = [&](int m, int i) {
+            i = i < nsteps ? i : nsteps - 1;
+            const float* p = abase + (size_t)(16 * m) * ci + (wave + 8 * i) * 32;
+            an[m][0] = *reinterpret_cast<const float4*>(p);
+            an[m][1] = *reinterpret_cast<const float4*>(p + 4);
+        };
+        auto loadB = [&](int set, int i) {
+            i = i < nsteps ? i : nsteps - 1;
+#pragma unroll
+            for (int n = 0; n < NC; ++n)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bb[set][n][p] = bp[((size_t)n * KS2 + wave + 8 * i) * 192 + p * 64];
+        };
+        auto step = [&](int set, int i) {
+            loadB(set ^ 1, i + 1);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                uint4 q0, q1, q2;
+                split_pair(an[m][0].x, an[m][0].y, q0.x, q1.x, q2.x);
+                split_pair(an[m][0].z, an[m][0].w, q0.y, q1.y, q2.y);
+                split_pair(an[m][1].x, an[m][1].y, q0.z, q1.z, q2.z);
+                split_pair(an[m][1].z, an[m][1].w, q0.w, q1.w, q2.w);
+                loadA(m, i + 1);                       // the same registers, one whole step ahead of their use
+                const bf16x8 a0 = __builtin_bit_cast(bf16x8, q0), a1 = __builtin_bit_cast(bf16x8, q1),
+                             a2 = __builtin_bit_cast(bf16x8, q2);
+#pragma unroll
+                for (int term = 0; term < 6; ++term) {
+                    const int pa = term == 0 ? 2 : (term == 1 || term == 3) ? 1 : 0;
+                    const int pb = term == 2 ? 2 : (term == 1 || term == 4) ? 1 : 0;
+                    const bf16x8 a = pa == 2 ? a2 : (pa == 1 ? a1 : a0);
+#pragma unroll
+                    for (int n = 0; n < NC; ++n)
+                        zp[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, bb[set][n][pb]), zp[m][n], 0, 0, 0);
+                }
+            }
+        };
+#pragma unroll
+        for (int m = 0; m < MT; ++m) loadA(m, 0);
+        loadB(0, 0);
+        for (int i = 0; i < nsteps; i += 2) {
+            step(0, i);
+            step(1, i + 1);
+        }
+    }
+    STAMP(1);
+    // reduce the 8 partial tiles; wave m (< MT) ends up with the 16 rows of row tile m
+    f32x4 z[NC];
+#pragma unroll
+    for (int n = 0; n < NC; ++n) z[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+        for (int mm = 0; mm < MH; ++mm)
+#pragma unroll
+            for (int n = 0; n < NC; ++n)
+                *reinterpret_cast<f32x4*>(smem + (size_t)((wave * MH + mm) * NC + n) * FRAG + lane * 16) = zp[hf * MH + mm][n];
+        __syncthreads();
+        if (wave >= hf * MH && wave < (hf + 1) * MH) {
+            const int mm = wave - hf * MH;
+#pragma unroll
+            for (int n = 0; n < NC; ++n)
+#pragma unroll
+                for (int src = 0; src < 8; ++src) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(smem + (size_t)((src * MH + mm) * NC + n) * FRAG + lane * 16);
+                    z[n] += t;
+                }
+        }
+        __syncthreads();
+    }
+
+    STAMP(2);
+    // column sums over the clip's rows: in-lane -> across the four row groups of the wave -> across waves (LDS)
+    auto colsum = [&](const float (&v)[NC], int stage, float (&tot)[NC]) {
+#pragma unroll
+        for (int n = 0; n < NC; ++n) {
+            float x = v[n];
+            x += __shfl_xor(x, 16);
+            x += __shfl_xor(x, 32);
+            if (kg == 0) red[stage][wave][16 * n + r16] = x;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < NC; ++n) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < MT; ++w) t += red[stage][w][16 * n + r16];
+            tot[n] = t;
+        }
+    };
+    const bool wv = wave < MT;
+    float v[NC], tot[NC], mu[NC], rs[NC];
+    // ---- phase 2: InstanceNorm, LeakyReLU, BRH, loss and their backward ----
+#pragma unroll
+    for (int n = 0; n < NC; ++n) {
+        const int c = 16 * n + r16;
+        const float bv = (c < C && bias) ? bias[c] : 0.f;
+        float sacc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            z[n][e] += bv;
+            if (wv && 16 * wave + 4 * kg + e < Tp) sacc += z[n][e];
+        }
+        v[n] = sacc;
+    }
+    colsum(v, 0, tot);
+#pragma unroll
+    for (int n = 0; n < NC; ++n) {
+        mu[n] = tot[n] * invT;
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (wv && 16 * wave + 4 * kg + e < Tp) { const float d = z[n][e] - mu[n]; q += d * d; }
+        v[n] = q;
+    }
+    colsum(v, 1, tot);
+#pragma unroll
+    for (int n = 0; n < NC; ++n) {
+        rs[n] = 1.0f / sqrtf(tot[n] * invT + 1e-5f);
+        float am = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float u = (z[n][e] - mu[n]) * rs[n];
+            z[n][e] = u;                                   // z now holds the normalised pre-activation
+            if (wv && 16 * wave + 4 * kg + e < Tp) am += (u > 0.f ? u : 0.2f * u);
+        }
+        v[n] = am;
+    }
+    colsum(v, 2, tot);
+    if (wave == 0 && kg == 0) {
+#pragma unroll
+        for (int n = 0; n < NC; ++n) mean_s[16 * n + r16] = (16 * n + r16 < C) ? tot[n] * invT : 0.f;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int c = lane;
+        float lterm = 0.f, dp = 0.f, p = 0.f;
+        if (c < nbits) {
+            p = tanhf(mean_s[2 * c] - mean_s[2 * c + 1]);
+            const float tg = target[clip * nbits + c];
+            const float inv = 1.0f / (float)nbits;
+            if (loss_kind == 0) {                       // push_extremes (losses.py:38-42)
+                lterm = ((p - tg) * (p - tg) - 0.1f * fabsf(p)) * inv;
+                dp = (2.f * (p - tg) - 0.1f * ((p > 0.f) ? 1.f : (p < 0.f ? -1.f : 0.f))) * inv;
+            } else if (loss_kind == 1) {                // mse
+                lterm = (p - tg) * (p - tg) * inv;
+                dp = 2.f * (p - tg) * inv;
+            } else if (loss_kind == 2) {                // hinge
+                const float hh = 1.f - p * tg;
+                lterm = (hh > 0.f ? hh : 0.f) * inv;
+                dp = (hh > 0.f ? -tg : 0.f) * inv;
+            } else if (loss_kind == 3) {                // sign
+                const float hh = -p * tg;
+                lterm = (hh > 0.f ? hh : 0.f) * inv;
+                dp = (hh > 0.f ? -tg : 0.f) * inv;
+            } else if (loss_kind == 4) {                // push_sigmoid (losses.py:55-59)
+                lterm = ((p - tg) * (p - tg) - 0.1f * fabsf(p - 0.5f)) * inv;
+                dp = (2.f * (p - tg) - 0.1f * ((p > 0.5f) ? 1.f : (p < 0.5f ? -1.f : 0.f))) * inv;
+            } else {                                    // ber: no gradient (losses.py:90-92)
+                const float sp = (p > 0.f) ? 1.f : (p < 0.f ? -1.f : 0.f), st_ = (tg > 0.f) ? 1.f : (tg < 0.f ? -1.f : 0.f);
+                lterm = (sp != st_ ? 1.f : 0.f) * inv;
+                dp = 0.f;
+            }
+            const float dpre = dp * (1.f - p * p);      // tanh'
+            dm[2 * c] = dpre; dm[2 * c + 1] = -dpre;
+            if (g == 0) pred[clip * nbits + c] = p;
+        }
+        const float L = wave_sum(lterm);
+        if (g == 0 && lane == 0) {
+            loss_out[clip] = L;
+            const float bl = best_loss[clip];
+            const int imp = L < bl;
+            improved[clip] = imp;
+            if (imp) best_loss[clip] = L;
+            if (step && clip == 0) *step += 1;
+        }
+    }
+    // zero the fragment image (columns C..63 and padding rows stay zero)
+    for (int i = tid; i < IMG / 16; i += 512) reinterpret_cast<uint4*>(img)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    float ga[NC], v2[NC], tot2[NC];
+#pragma unroll
+    for (int n = 0; n < NC; ++n) {
+        const int c = 16 * n + r16;
+        ga[n] = (c < C) ? dm[c] * invT : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (wv && 16 * wave + 4 * kg + e < Tp) { const float du = ga[n] * (z[n][e] > 0.f ? 1.f : 0.2f); s1 += du; s2 += du * z[n][e]; }
+        v[n] = s1; v2[n] = s2;
+    }
+    colsum(v, 3, tot);
+    colsum(v2, 4, tot2);
+    if (wv) {
+#pragma unroll
+        for (int n = 0; n < NC; ++n) {
+            const int c = 16 * n + r16;
+            const float m1 = tot[n] * invT, m2 = tot2[n] * invT;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = 16 * wave + 4 * kg + e;
+                if (row < Tp && c < C) {
+                    const float du = ga[n] * (z[n][e] > 0.f ? 1.f : 0.2f);
+                    const float dz = rs[n] * (du - m1 - z[n][e] * m2);
+                    unsigned p0, p1, p2;
+                    split_pair(dz, 0.f, p0, p1, p2);
+                    // A-fragment order of the data-gradient GEMM: k = c
+                    unsigned char* d = img + (size_t)((c >> 5) * 3 * MT + wave) * FRAG + ((row & 15) + 16 * ((c & 31) >> 3)) * 16 + (c & 7) * 2;
+                    *reinterpret_cast<unsigned short*>(d) = (unsigned short)p0;
+                    *reinterpret_cast<unsigned short*>(d + MT * FRAG) = (unsigned short)p1;
+                    *reinterpret_cast<unsigned short*>(d + 2 * MT * FRAG) = (unsigned short)p2;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    STAMP(3);
+    // ---- phase 3: dL/dh = dZ_last * W, 32 columns per wave, fused backward of the previous block ----
+    f32x4 acc[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) { acc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int ntb = g * 16 + 2 * wave;                  // first 16-column tile of this wave
+#pragma unroll
+    for (int t = 0; t < KSC; ++t) {
+        bf16x8 b[2][3], a[MT][3];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                b[n][p] = __builtin_bit_cast(bf16x8, WTpk[(((size_t)(ntb + n) * KSC + t) * 3 + p) * 64 + lane]);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) a[m][p] = *reinterpret_cast<const bf16x8*>(img + (size_t)((t * 3 + p) * MT + m) * FRAG + lane * 16);
+#pragma unroll
+        for (int term = 0; term < 6; ++term) {
+            const int pa = term == 0 ? 2 : (term == 1 || term == 3) ? 1 : 0;
+            const int pb = term == 2 ? 2 : (term == 1 || term == 4) ? 1 : 0;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][pa], b[n][pb], acc[m][n], 0, 0, 0);
+        }
+    }
+    STAMP(4);
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int col = (ntb + n) * 16 + r16;
+        const float rsp = rstd_prev[(size_t)clip * ci + col];
+        float s1 = 0.f, s2 = 0.f;
+        float u[MT][4];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = m * 16 + 4 * kg + e;
+                float du = 0.f, uv = 0.f;
+                if (row < Tp) {
+                    const float av = hin[(size_t)(bm + row) * ci + col];
+                    uv = av > 0.f ? av : av * 5.0f;                 // invert LeakyReLU(0.2)
+                    du = acc[m][n][e] * (av > 0.f ? 1.f : 0.2f);
+                }
+                acc[m][n][e] = du;
+                u[m][e] = uv;
+                s1 += du;
+                s2 += du * uv;
+            }
+        s1 += __shfl_xor(s1, 16);
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 16);
+        s2 += __shfl_xor(s2, 32);
+        const float m1 = s1 * invT, m2 = s2 * invT;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = m * 16 + 4 * kg + e;
+                dZ[(size_t)(bm + row) * ci + col] = row < Tp ? rsp * (acc[m][n][e] - m1 - u[m][e] * m2) : 0.f;
+            }
+    }
+    STAMP(5);
+}
+
+bool readout_x3_supported(int nwm, int ci, int C) { return nwm >= 1 && nwm <= 4 && ci % 512 == 0 && C >= 2 && C <= 64 && C % 2 == 0; }
+
+// Wpk: x3_pack of the last conv's weights zero-padded to a multiple of 16 rows ([16*ceil(C/16)][ci]);
+// WTpk: x3_pack of their transpose ([ci][C], k padded to 64)
+void launch_readout_x3(const float* hin, int ci, const void* Wpk, const float* bias, const void* WTpk, const float* rstd_prev,
+                       const float* target, float* pred, float* loss, float* best_loss, int* improved, int* step, float* dZ,
+                       int B, int nwm, int Tp, int C, int nbits, int loss_kind, hipStream_t st) {
+    const int G = ci / 256, nc = (C + 15) / 16;
+#define RK(M_, N_) hipLaunchKernelGGL((readout_x3_kernel<M_, N_>), dim3(B * G), dim3(512), 0, st, hin, ci, (const u32x4*)Wpk, bias, \
+                                      (const u32x4*)WTpk, rstd_prev, target, pred, loss, best_loss, improved, step, dZ, Tp, C,       \
+                                      nbits, loss_kind, G, B * G)
+#define RN(M_) switch (nc) { case 1: RK(M_, 1); break; case 2: RK(M_, 2); break; case 3: RK(M_, 3); break; default: RK(M_, 4); break; }
+    switch (nwm) { case 1: RN(1) break; case 2: RN(2) break; case 3: RN(3) break; default: RN(4) break; }
+#undef RN
+#undef RK
 }
 
 }  // namespace aware
