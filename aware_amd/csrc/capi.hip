@@ -442,6 +442,11 @@ struct DetBufs {
     int tail;         // 1: the last conv was left as partials for the fused tail kernel
 };
 constexpr int kTailSplit = 4;
+// slabs of split-K partials of the last conv: 4 from the split-K GEMM, Cin/128 from the fused forward epilogue
+static int zpart_slabs(const aware_detector* d) {
+    const int s = d->n_layers >= 1 ? d->ch[d->n_layers - 1] / 128 : 0;
+    return s > kTailSplit ? s : kTailSplit;
+}
 static void carve_det(Carver& c, const aware_batch* b, const aware_detector* d, DetBufs& o) {
     o.xm = c.take<float>((size_t)b->NF * 128);
     o.x0 = c.take<float>((size_t)b->NP * 128);
@@ -454,14 +459,14 @@ static void carve_det(Carver& c, const aware_batch* b, const aware_detector* d, 
     o.mstride = (b->max_frames + 31) / 32;
     o.mpart = c.take<float>((size_t)b->B * o.mstride * 256);
     o.pred = c.take<float>((size_t)b->B * d->nbits);
-    o.zpart = c.take<float>((size_t)kTailSplit * b->NP * d->ch[d->n_layers]);
+    o.zpart = c.take<float>((size_t)zpart_slabs(d) * b->NP * d->ch[d->n_layers]);
     o.tail = 0;
 }
 static size_t det_bytes(const aware_batch* b, const aware_detector* d) {
     size_t f = (size_t)b->NF * 128 + (size_t)b->NP * 128 + (size_t)b->B * (128 * 4 + 4 + d->nbits) +
                (size_t)b->B * ((b->max_frames + 31) / 32) * 256;
     for (int l = 0; l < d->n_layers; ++l) f += (size_t)(b->NP + b->B) * d->ch[l + 1];
-    f += (size_t)kTailSplit * b->NP * d->ch[d->n_layers];
+    f += (size_t)zpart_slabs(d) * b->NP * d->ch[d->n_layers];
     return f * sizeof(float) + 256 * (8 + 2 * d->n_layers);
 }
 
@@ -494,8 +499,9 @@ static int det_forward(const aware_detector* d, const aware_batch* b, const floa
         } else if (nwm && co >= 128) {
             // conv + InstanceNorm + LeakyReLU in one kernel (clip-aligned tiles)
             if (get_gemm_clip_config() == 4 && d->wpk[l] && gemm_clip_x3_supported(nwm, co, ci, ci)) {
+                const bool emit = skip_last && l == d->n_layers - 2;   // + split-K partials of the last conv
                 launch_gemm_clip_x3(x, ci, d->wpk[l], d->bias[l], o.act[l], co, b->B, nwm, b->uniform_tp, co, ci, 1, o.rstd[l],
-                                    nullptr, st);
+                                    nullptr, st, emit ? d->lastpk : nullptr, emit ? o.zpart : nullptr, d->ch[d->n_layers]);
                 LAUNCHCHK(); PROF(K_GEMM_X3_FWD);
             } else {
                 launch_gemm_clip(x, ci, d->w[l], ci, d->bias[l], o.act[l], co, b->B, nwm, b->uniform_tp, co, ci, 1, o.rstd[l],
@@ -749,7 +755,8 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
     // one kernel for the last conv block, the BRH head, the loss, their backward and the data gradient of the last
     // conv (uniform batches, bf16x3 configuration); otherwise split-K GEMM + tail kernel + data-gradient GEMM
     const bool fused_readout = get_gemm_clip_config() == 4 && nwm && nl >= 2 && d->lastpk && e->target &&
-                               readout_x3_supported(nwm, d->ch[nl - 1], d->ch[nl]) && d->ch[nl - 1] >= 128;
+                               readout_x3_supported(nwm, d->ch[nl - 1], d->ch[nl]) && d->wpk[nl - 2] &&
+                               gemm_clip_x3_supported(nwm, d->ch[nl - 1], d->ch[nl - 2], d->ch[nl - 2]);
     int rc = det_forward(d, b, e->mag, e->db, st, fused_readout);
     if (rc) return rc;
     // :109 loss, :120-122 best tracking, gradient seed
@@ -759,9 +766,9 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
     bool dz_ready = false;      // dA already holds dL/dZ of layer l (fused into the producing kernel)
     int l_top = nl - 1;         // first layer the backward loop below still has to differentiate
     if (fused_readout) {
-        launch_readout_x3(e->db.act[nl - 2], d->ch[nl - 1], d->lastpk, d->bias[nl - 1], d->lastTpk, e->db.rstd[nl - 2],
-                          e->target, e->db.pred, e->loss, e->best_loss, e->improved, step_ptr, dA, b->B, nwm,
-                          b->uniform_tp, d->ch[nl], d->nbits, e->cfg.loss, st);
+        launch_readout_x3(e->db.act[nl - 2], d->ch[nl - 1], e->db.zpart, d->ch[nl - 1] / 128, d->bias[nl - 1], d->lastTpk,
+                          e->db.rstd[nl - 2], e->target, e->db.pred, e->loss, e->best_loss, e->improved, step_ptr, dA, b->B,
+                          nwm, b->uniform_tp, d->ch[nl], d->nbits, e->cfg.loss, st);
         dz_ready = true;
         l_top = nl - 2;
     } else if (e->db.tail) {

@@ -255,12 +255,12 @@ __device__ __forceinline__ void clip_epilogue(const f32x16& acc, float (*red1)[3
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int r = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            du[e] = 0.f; u[e] = 0.f;
-            if (cok && r < Tp) {
-                const float av = act[(size_t)(bm + r) * ldc + col];
-                u[e] = av > 0.f ? av : av * 5.0f;                 // invert LeakyReLU(0.2)
-                du[e] = acc[e] * (av > 0.f ? 1.f : 0.2f);
-            }
+            // loaded for every row of the 32-row groups (padding rows exist and hold zeros): a per-element branch
+            // would serialise the loads behind their waits
+            const float av = act[(size_t)(bm + r) * ldc + (cok ? col : 0)];
+            const bool valid = cok && r < Tp;
+            u[e] = valid ? (av > 0.f ? av : av * 5.0f) : 0.f;                 // invert LeakyReLU(0.2)
+            du[e] = valid ? acc[e] * (av > 0.f ? 1.f : 0.2f) : 0.f;
             s1 += du[e]; s2 += du[e] * u[e];
         }
         s1 += __shfl_xor(s1, 32);

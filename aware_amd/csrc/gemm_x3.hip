@@ -75,7 +75,7 @@ __device__ __forceinline__ void split_pair(float x, float y, unsigned& p0, unsig
     p2 = cvt_pk_bf16(sx, sy);
 }
 
-enum { X3_PLAIN = 0, X3_FWD = 1, X3_BWD = 2 };
+enum { X3_PLAIN = 0, X3_FWD = 1, X3_BWD = 2, X3_FWD_LAST = 3 };   // 3: FWD + split-K partials of the next (last, skinny) conv
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -106,7 +106,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_clip_x3_kernel(const float* __re
                                                                  const u32x4* __restrict__ Bpk, const float* __restrict__ bias,
                                                                  float* __restrict__ C, int ldc, int Tp, int N, int K,
                                                                  int tiles_n, int ntiles, float* __restrict__ rstd_io,
-                                                                 const float* __restrict__ act) {
+                                                                 const float* __restrict__ act,
+                                                                 const u32x4* __restrict__ Lpk, float* __restrict__ zpart,
+                                                                 int CL) {
     constexpr int NT = 64 * NW;
     constexpr int NTW = 8 / NW;           // 16-column tiles per wave (slab = 128 columns)
     constexpr int MT = 2 * RG;            // 16-row tiles per clip
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_clip_x3_kernel(const float* __re
                     const int row = m * 16 + 4 * kg + e;
                     C[(size_t)(bm + row) * ldc + col] = row < Tp ? acc[m][n][e] + bv : 0.f;
                 }
-        } else if (EPI == X3_FWD) {
+        } else if (EPI == X3_FWD || EPI == X3_FWD_LAST) {
             const float bv = bias ? bias[col] : 0.f;
             float s = 0.f;
 #pragma unroll
@@ -272,7 +274,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_clip_x3_kernel(const float* __re
                 for (int e = 0; e < 4; ++e) {
                     const int row = m * 16 + 4 * kg + e;
                     const float u = (acc[m][n][e] - mean) * rs;
-                    C[(size_t)(bm + row) * ldc + col] = row < Tp ? (u > 0.f ? u : 0.2f * u) : 0.f;
+                    const float o = row < Tp ? (u > 0.f ? u : 0.2f * u) : 0.f;
+                    acc[m][n][e] = o;
+                    C[(size_t)(bm + row) * ldc + col] = o;
                 }
         } else {
             // X3_BWD: acc = dL/dA of the previous block's output (read from `act`, post-activation);
@@ -285,12 +289,11 @@ __global__ __launch_bounds__(64 * NW) void gemm_clip_x3_kernel(const float* __re
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int row = m * 16 + 4 * kg + e;
-                    float du = 0.f, uv = 0.f;
-                    if (row < Tp) {
-                        const float av = act[(size_t)(bm + row) * ldc + col];
-                        uv = av > 0.f ? av : av * 5.0f;                 // invert LeakyReLU(0.2)
-                        du = acc[m][n][e] * (av > 0.f ? 1.f : 0.2f);
-                    }
+                    // unconditional load (padding rows exist and hold zeros): a branch here would serialise the loads
+                    const float av = act[(size_t)(bm + row) * ldc + col];
+                    const bool valid = row < Tp;
+                    const float uv = valid ? (av > 0.f ? av : av * 5.0f) : 0.f;                 // invert LeakyReLU(0.2)
+                    const float du = valid ? acc[m][n][e] * (av > 0.f ? 1.f : 0.2f) : 0.f;
                     acc[m][n][e] = du;
                     u[m][e] = uv;
                     s1 += du;
@@ -310,15 +313,74 @@ __global__ __launch_bounds__(64 * NW) void gemm_clip_x3_kernel(const float* __re
                 }
         }
     }
+    if (EPI == X3_FWD_LAST && NTW == 1) {
+        // acc[m][0][e] holds this block's output (zero in padding rows).  The next conv block is the skinny last one
+        // (CL <= 64 channels): its K = this N is split over the column slabs, so this workgroup contributes the partial
+        // z_part[slab] = out[:, slab] * Wlast[:, slab]^T.  The output tile is re-laid as A fragments (k = column) in LDS.
+        __syncthreads();                                  // every wave is done with the staging buffers
+        {
+            const int k = 16 * wave + r16;
+            unsigned char* d0 = lds + (size_t)((k >> 5) * 3 * MT) * FRAG + (16 * ((k & 31) >> 3)) * 16 + (k & 7) * 2;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    unsigned p0, p1, p2;
+                    split_pair(acc[m][0][e], 0.f, p0, p1, p2);
+                    unsigned char* d = d0 + m * FRAG + (4 * kg + e) * 16;
+                    *reinterpret_cast<unsigned short*>(d) = (unsigned short)p0;
+                    *reinterpret_cast<unsigned short*>(d + MT * FRAG) = (unsigned short)p1;
+                    *reinterpret_cast<unsigned short*>(d + 2 * MT * FRAG) = (unsigned short)p2;
+                }
+        }
+        __syncthreads();
+        if (wave < MT) {
+            const int slab = bn >> 7, KS2L = N >> 5, ncl = (CL + 15) >> 4;
+            f32x4 zt[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) zt[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int t = 0; t < 4; ++t) {                 // not unrolled: keeps the kernel at 4 waves per SIMD
+                bf16x8 a[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const bf16x8*>(lds + (size_t)((t * 3 + p) * MT + wave) * FRAG + lane * 16);
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    if (n < ncl) {
+                        bf16x8 b[3];
+#pragma unroll
+                        for (int p = 0; p < 3; ++p)
+                            b[p] = __builtin_bit_cast(bf16x8, Lpk[(((size_t)n * KS2L + 4 * slab + t) * 3 + p) * 64 + lane]);
+                        zt[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], zt[n], 0, 0, 0);
+                        zt[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], zt[n], 0, 0, 0);
+                        zt[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], zt[n], 0, 0, 0);
+                        zt[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], zt[n], 0, 0, 0);
+                        zt[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], zt[n], 0, 0, 0);
+                        zt[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], zt[n], 0, 0, 0);
+                    }
+            }
+            float* zp = zpart + (size_t)slab * ((size_t)(ntiles / tiles_n) * 32 * RG * CL) + (size_t)(bm + 16 * wave + 4 * kg) * CL;
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                if (n < ncl && 16 * n + r16 < CL) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) zp[(size_t)e * CL + 16 * n + r16] = zt[n][e];
+                }
+        }
+    }
 }
 
 void launch_gemm_clip_x3(const float* A, int lda, const void* Bpk, const float* bias, float* C, int ldc, int B, int nwm,
-                         int Tp, int N, int K, int epi, float* rstd_io, const float* act, hipStream_t st) {
+                         int Tp, int N, int K, int epi, float* rstd_io, const float* act, hipStream_t st,
+                         const void* lastpk, float* zpart, int CL) {
     const int tn = N / 128;
+    if (epi == X3_FWD && lastpk && zpart) epi = X3_FWD_LAST;
 #define XK(M_, E_) hipLaunchKernelGGL((gemm_clip_x3_kernel<M_, E_, 8>), dim3(tn * B), dim3(512), 0, st, A, lda,          \
-                                      (const u32x4*)Bpk, bias, C, ldc, Tp, N, K, tn, tn * B, rstd_io, act)
+                                      (const u32x4*)Bpk, bias, C, ldc, Tp, N, K, tn, tn * B, rstd_io, act,                \
+                                      (const u32x4*)lastpk, zpart, CL)
 #define XM(E_) switch (nwm) { case 1: XK(1, E_); break; case 2: XK(2, E_); break; case 3: XK(3, E_); break; default: XK(4, E_); break; }
-    if (epi == X3_FWD) { XM(X3_FWD) } else if (epi == X3_BWD) { XM(X3_BWD) } else { XM(X3_PLAIN) }
+    if (epi == X3_FWD) { XM(X3_FWD) } else if (epi == X3_BWD) { XM(X3_BWD) } else if (epi == X3_FWD_LAST) { XM(X3_FWD_LAST) }
+    else { XM(X3_PLAIN) }
 #undef XM
 #undef XK
 }
@@ -348,7 +410,8 @@ extern "C" int aware_debug_stamps(unsigned long long* out) { return (int)hipMemc
 #endif
 template <int RG, int NC>
 __global__ __launch_bounds__(512) void readout_x3_kernel(const float* __restrict__ hin, int ci,
-                                                          const u32x4* __restrict__ Wpk, const float* __restrict__ bias,
+                                                          const float* __restrict__ zpart, int nslab, size_t slab_stride,
+                                                          const float* __restrict__ bias,
                                                           const u32x4* __restrict__ WTpk, const float* __restrict__ rstd_prev,
                                                           const float* __restrict__ target, float* __restrict__ pred,
                                                           float* __restrict__ loss_out, float* __restrict__ best_loss,
@@ -356,13 +419,10 @@ __global__ __launch_bounds__(512) void readout_x3_kernel(const float* __restrict
                                                           float* __restrict__ dZ, int Tp, int C, int nbits, int loss_kind,
                                                           int G, int ntiles) {
     constexpr int MT = 2 * RG;
-    constexpr int MH = RG;
     constexpr int FRAG = 1024;
     constexpr int KSC = 2;                           // K32 steps of the data-gradient GEMM (C <= 64)
     constexpr int IMG = KSC * 3 * MT * FRAG;         // dZ_last as A fragments of the data-gradient GEMM
-    constexpr int PART = 8 * MH * NC * FRAG;         // split-K partial tiles of half the clip's rows, all 8 waves
-    __shared__ __attribute__((aligned(16))) unsigned char smem[IMG > PART ? IMG : PART];
-    unsigned char* const img = smem;
+    __shared__ __attribute__((aligned(16))) unsigned char img[IMG];
     __shared__ float red[6][8][64];
     __shared__ float mean_s[64], dm[64];
 
@@ -374,91 +434,25 @@ __global__ __launch_bounds__(512) void readout_x3_kernel(const float* __restrict
     const int r16 = lane & 15, kg = lane >> 4;
     const float invT = 1.0f / (float)Tp;
 
-    STAMP(0);
-    // ---- phase 1: z = h * W^T.  K is split over the 8 waves (K32 steps wave, wave+8, ...); every wave covers all
-    //      rows of the clip with A split in registers straight from global memory (no LDS staging) ----
-    f32x4 zp[MT][NC];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NC; ++n) zp[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int KS2 = ci >> 5;
-    {
-        const int nsteps = KS2 >> 3;                   // Cin % 512 == 0: an even number of steps per wave
-        const float* abase = hin + (size_t)(bm + r16) * ci + 8 * kg;
-        const u32x4* bp = Wpk + lane;
-        float4 an[MT][2];
-        u32x4 bb[2][NC][3];
-        auto loadA = [&](int m, int i) {
-            i = i < nsteps ? i : nsteps - 1;
-            const float* p = abase + (size_t)(16 * m) * ci + (wave + 8 * i) * 32;
-            an[m][0] = *reinterpret_cast<const float4*>(p);
-            an[m][1] = *reinterpret_cast<const float4*>(p + 4);
-        };
-        auto loadB = [&](int set, int i) {
-            i = i < nsteps ? i : nsteps - 1;
-#pragma unroll
-            for (int n = 0; n < NC; ++n)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) bb[set][n][p] = bp[((size_t)n * KS2 + wave + 8 * i) * 192 + p * 64];
-        };
-        auto step = [&](int set, int i) {
-            loadB(set ^ 1, i + 1);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                uint4 q0, q1, q2;
-                split_pair(an[m][0].x, an[m][0].y, q0.x, q1.x, q2.x);
-                split_pair(an[m][0].z, an[m][0].w, q0.y, q1.y, q2.y);
-                split_pair(an[m][1].x, an[m][1].y, q0.z, q1.z, q2.z);
-                split_pair(an[m][1].z, an[m][1].w, q0.w, q1.w, q2.w);
-                loadA(m, i + 1);                       // the same registers, one whole step ahead of their use
-                const bf16x8 a0 = __builtin_bit_cast(bf16x8, q0), a1 = __builtin_bit_cast(bf16x8, q1),
-                             a2 = __builtin_bit_cast(bf16x8, q2);
-#pragma unroll
-                for (int term = 0; term < 6; ++term) {
-                    const int pa = term == 0 ? 2 : (term == 1 || term == 3) ? 1 : 0;
-                    const int pb = term == 2 ? 2 : (term == 1 || term == 4) ? 1 : 0;
-                    const bf16x8 a = pa == 2 ? a2 : (pa == 1 ? a1 : a0);
-#pragma unroll
-                    for (int n = 0; n < NC; ++n)
-                        zp[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, bb[set][n][pb]), zp[m][n], 0, 0, 0);
-                }
-            }
-        };
-#pragma unroll
-        for (int m = 0; m < MT; ++m) loadA(m, 0);
-        loadB(0, 0);
-        for (int i = 0; i < nsteps; i += 2) {
-            step(0, i);
-            step(1, i + 1);
-        }
-    }
-    STAMP(1);
-    // reduce the 8 partial tiles; wave m (< MT) ends up with the 16 rows of row tile m
+    // ---- phase 1: z = sum of the split-K partials written by the previous block's kernel (X3_FWD_LAST);
+    //      wave m (< MT) holds the 16 rows of row tile m ----
     f32x4 z[NC];
 #pragma unroll
     for (int n = 0; n < NC; ++n) z[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (wave < MT) {
+        const float* zp = zpart + (size_t)(bm + 16 * wave + 4 * kg) * C;
+        for (int sl = 0; sl < nslab; ++sl) {
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
+            for (int n = 0; n < NC; ++n) {
+                const int c = 16 * n + r16 < C ? 16 * n + r16 : C - 1;       // clamped, not branched: loads stay batched
 #pragma unroll
-        for (int mm = 0; mm < MH; ++mm)
-#pragma unroll
-            for (int n = 0; n < NC; ++n)
-                *reinterpret_cast<f32x4*>(smem + (size_t)((wave * MH + mm) * NC + n) * FRAG + lane * 16) = zp[hf * MH + mm][n];
-        __syncthreads();
-        if (wave >= hf * MH && wave < (hf + 1) * MH) {
-            const int mm = wave - hf * MH;
-#pragma unroll
-            for (int n = 0; n < NC; ++n)
-#pragma unroll
-                for (int src = 0; src < 8; ++src) {
-                    const f32x4 t = *reinterpret_cast<const f32x4*>(smem + (size_t)((src * MH + mm) * NC + n) * FRAG + lane * 16);
-                    z[n] += t;
-                }
+                for (int e = 0; e < 4; ++e) z[n][e] += zp[(size_t)sl * slab_stride + (size_t)e * C + c];
+            }
         }
-        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < NC; ++n)
+            if (16 * n + r16 >= C) z[n] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-
     STAMP(2);
     // column sums over the clip's rows: in-lane -> across the four row groups of the wave -> across waves (LDS)
     auto colsum = [&](const float (&v)[NC], int stage, float (&tot)[NC]) {
@@ -646,12 +640,10 @@ __global__ __launch_bounds__(512) void readout_x3_kernel(const float* __restrict
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int row = m * 16 + 4 * kg + e;
-                float du = 0.f, uv = 0.f;
-                if (row < Tp) {
-                    const float av = hin[(size_t)(bm + row) * ci + col];
-                    uv = av > 0.f ? av : av * 5.0f;                 // invert LeakyReLU(0.2)
-                    du = acc[m][n][e] * (av > 0.f ? 1.f : 0.2f);
-                }
+                const float av = hin[(size_t)(bm + row) * ci + col];      // unconditional: see gemm_clip_x3_kernel
+                const bool valid = row < Tp;
+                const float uv = valid ? (av > 0.f ? av : av * 5.0f) : 0.f;                 // invert LeakyReLU(0.2)
+                const float du = valid ? acc[m][n][e] * (av > 0.f ? 1.f : 0.2f) : 0.f;
                 acc[m][n][e] = du;
                 u[m][e] = uv;
                 s1 += du;
@@ -673,16 +665,17 @@ __global__ __launch_bounds__(512) void readout_x3_kernel(const float* __restrict
     STAMP(5);
 }
 
-bool readout_x3_supported(int nwm, int ci, int C) { return nwm >= 1 && nwm <= 4 && ci % 512 == 0 && C >= 2 && C <= 64 && C % 2 == 0; }
+bool readout_x3_supported(int nwm, int ci, int C) { return nwm >= 1 && nwm <= 4 && ci % 256 == 0 && C >= 2 && C <= 64 && C % 2 == 0; }
 
-// Wpk: x3_pack of the last conv's weights zero-padded to a multiple of 16 rows ([16*ceil(C/16)][ci]);
-// WTpk: x3_pack of their transpose ([ci][C], k padded to 64)
-void launch_readout_x3(const float* hin, int ci, const void* Wpk, const float* bias, const void* WTpk, const float* rstd_prev,
-                       const float* target, float* pred, float* loss, float* best_loss, int* improved, int* step, float* dZ,
-                       int B, int nwm, int Tp, int C, int nbits, int loss_kind, hipStream_t st) {
+// zpart: [nslab][B*32*nwm][C] split-K partials of the last conv (written by launch_gemm_clip_x3 with lastpk/zpart);
+// WTpk: x3_pack of the last conv's transposed weights ([ci][C], k zero-padded to 64)
+void launch_readout_x3(const float* hin, int ci, const float* zpart, int nslab, const float* bias, const void* WTpk,
+                       const float* rstd_prev, const float* target, float* pred, float* loss, float* best_loss, int* improved,
+                       int* step, float* dZ, int B, int nwm, int Tp, int C, int nbits, int loss_kind, hipStream_t st) {
     const int G = ci / 256, nc = (C + 15) / 16;
-#define RK(M_, N_) hipLaunchKernelGGL((readout_x3_kernel<M_, N_>), dim3(B * G), dim3(512), 0, st, hin, ci, (const u32x4*)Wpk, bias, \
-                                      (const u32x4*)WTpk, rstd_prev, target, pred, loss, best_loss, improved, step, dZ, Tp, C,       \
+    const size_t slab_stride = (size_t)B * 32 * nwm * C;
+#define RK(M_, N_) hipLaunchKernelGGL((readout_x3_kernel<M_, N_>), dim3(B * G), dim3(512), 0, st, hin, ci, zpart, nslab, slab_stride, \
+                                      bias, (const u32x4*)WTpk, rstd_prev, target, pred, loss, best_loss, improved, step, dZ, Tp, C, \
                                       nbits, loss_kind, G, B * G)
 #define RN(M_) switch (nc) { case 1: RK(M_, 1); break; case 2: RK(M_, 2); break; case 3: RK(M_, 3); break; default: RK(M_, 4); break; }
     switch (nwm) { case 1: RN(1) break; case 2: RN(2) break; case 3: RN(3) break; default: RN(4) break; }

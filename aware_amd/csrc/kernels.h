@@ -84,14 +84,17 @@ int get_gemm_clip_config();
 size_t x3_packed_bytes(int N, int K);
 void x3_pack(const float* Wt, int N, int K, uint16_t* out);      // host: [N][K] f32 -> fragment-ordered bf16 planes
 bool gemm_clip_x3_supported(int nwm, int N, int K, int lda);
+// lastpk/zpart (forward epilogue only): also emit the split-K partials [N/128][B*32*nwm][CL] of the next, last conv
+// block (x3_pack of its weights zero-padded to a multiple of 16 rows), consumed by launch_readout_x3
 void launch_gemm_clip_x3(const float* A, int lda, const void* Bpk, const float* bias, float* C, int ldc, int B, int nwm,
-                         int Tp, int N, int K, int epi, float* rstd_io, const float* act, hipStream_t st);
+                         int Tp, int N, int K, int epi, float* rstd_io, const float* act, hipStream_t st,
+                         const void* lastpk = nullptr, float* zpart = nullptr, int CL = 0);
 // fused read-out of the embed loop: last conv block + BRH + loss + their backward + data gradient of the last conv
 // + backward of the previous block's norm/activation (uniform batches; see gemm_x3.hip)
 bool readout_x3_supported(int nwm, int ci, int C);
-void launch_readout_x3(const float* hin, int ci, const void* Wpk, const float* bias, const void* WTpk, const float* rstd_prev,
-                       const float* target, float* pred, float* loss, float* best_loss, int* improved, int* step, float* dZ,
-                       int B, int nwm, int Tp, int C, int nbits, int loss_kind, hipStream_t st);
+void launch_readout_x3(const float* hin, int ci, const float* zpart, int nslab, const float* bias, const void* WTpk,
+                       const float* rstd_prev, const float* target, float* pred, float* loss, float* best_loss, int* improved,
+                       int* step, float* dZ, int B, int nwm, int Tp, int C, int nbits, int loss_kind, hipStream_t st);
 // mel block: InstanceNorm over time, per-clip GlobalStandardize, AvgPool(2,2)
 void launch_mel_norm_fwd(const float* xm, const int* frame_off, const int* pool_off, float* x0, float* stats,
                          float* gstat, float* part, int pstride, int B, int max_frames, hipStream_t st);
