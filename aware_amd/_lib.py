@@ -118,6 +118,8 @@ def load_library():
         fn.argtypes = args
     if os.environ.get("AWARE_TUNE_CLIP"):          # development knob, see aware_tune() in the header
         lib.aware_tune(1, int(os.environ["AWARE_TUNE_CLIP"]))
+    if os.environ.get("AWARE_TUNE_READOUT"):
+        lib.aware_tune(2, int(os.environ["AWARE_TUNE_READOUT"]))
     _lib = lib
     return lib
 

@@ -91,8 +91,10 @@ struct aware_detector {
 
 extern "C" int aware_version(void) { return 100; }
 // tuning knob (not part of the drop-in surface): K-tile / buffering of the clip-aligned GEMM
+static int g_fused_readout = 1;
 extern "C" int aware_tune(int key, int value) {
     if (key == 1) { set_gemm_clip_config(value); return AWARE_OK; }
+    if (key == 2) { g_fused_readout = value != 0; return AWARE_OK; }
     return AWARE_E_BADARG;
 }
 extern "C" const char* aware_last_hip_error(void) { return g_last_err.c_str(); }
@@ -754,7 +756,7 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
     const int nwm = clip_tile_groups(b);
     // one kernel for the last conv block, the BRH head, the loss, their backward and the data gradient of the last
     // conv (uniform batches, bf16x3 configuration); otherwise split-K GEMM + tail kernel + data-gradient GEMM
-    const bool fused_readout = get_gemm_clip_config() == 4 && nwm && nl >= 2 && d->lastpk && e->target &&
+    const bool fused_readout = g_fused_readout && get_gemm_clip_config() == 4 && nwm && nl >= 2 && d->lastpk && e->target &&
                                readout_x3_supported(nwm, d->ch[nl - 1], d->ch[nl]) && d->wpk[nl - 2] &&
                                gemm_clip_x3_supported(nwm, d->ch[nl - 1], d->ch[nl - 2], d->ch[nl - 2]);
     int rc = det_forward(d, b, e->mag, e->db, st, fused_readout);

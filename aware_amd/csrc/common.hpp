@@ -106,6 +106,16 @@ __device__ __forceinline__ float ola_envelope(const PlanDev& pl, int p, int T) {
     return pl.env_tab[768 + (p & 255)];
 }
 
+// Index of that table entry (T >= 4), branch-free so that a batch of envelope loads can be issued together;
+// clamped to the table for positions a caller masks out anyway.
+__device__ __forceinline__ int ola_envelope_index(int p, int T) {
+    const int q = p - kHop * T;
+    int idx = 768 + (p & 255);
+    idx = p < 768 ? p : idx;
+    idx = q >= 0 ? 1536 + q : idx;
+    return min(max(idx, 0), 2303);
+}
+
 // balanced split of `nblk` hop blocks into nseg = ceil(nblk/13) segments
 __device__ __forceinline__ void synth_segment(int nblk, int seg, int& nseg, int& jb0, int& jb1) {
     nseg = (nblk + kSynthBlocks - 1) / kSynthBlocks;

@@ -123,27 +123,47 @@ __global__ __launch_bounds__(kThreads) void analysis_kernel(AnalysisArgs a) {
     // ---- stage the signal chunk: padded positions [256*t0, 256*t0 + 256*(nfr-1)+1024) --
     const int p0 = kHop * t0;
     const int cnt = kHop * (nfr - 1) + kNfft;
-    for (int i = tid; i < cnt; i += kThreads) {
-        const int p = p0 + i;
-        int src = p - kHalf;
-        float v;
-        if (MODE == AN_NORM) {
-            if (src < 0) src = -src;
-            if (src >= n) src = 2 * (n - 1) - src;
-            v = x[src];
-            if (a.pmax) { v = v / m; if (a.double_norm) v = v / m2; }
-        } else {
-            // adjoint of (trim, / envelope): zero outside the kept region
-            if (src >= 0 && src < n) {
-                float g = x[src];
-                if ((unsigned)src == kmax) g -= adot * smax;
-                g = g / (m * m2);
-                v = g / ola_envelope(a.plan, p, T);
-            } else {
-                v = 0.f;
+    {
+        // all loads of the chunk are issued before any of them is used (a load inside a per-sample branch
+        // would wait for its own latency 19 times over)
+        constexpr int NIT = kChunk / kThreads;
+        const bool small_t = T < 4;                    // clips shorter than the envelope tables assume
+        float xin[NIT], env[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int p = p0 + tid + kThreads * it;
+            int src = p - kHalf;
+            if (MODE == AN_NORM) {
+                if (src < 0) src = -src;
+                if (src >= n) src = 2 * (n - 1) - src;
+            }
+            xin[it] = x[min(max(src, 0), n - 1)];
+            if (MODE == AN_ADJ) env[it] = small_t ? 1.f : a.plan.env_tab[ola_envelope_index(p, T)];
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + kThreads * it;
+            if (i < cnt) {
+                const int p = p0 + i;
+                const int src = p - kHalf;
+                float v;
+                if (MODE == AN_NORM) {
+                    v = xin[it];
+                    if (a.pmax) { v = v / m; if (a.double_norm) v = v / m2; }
+                } else {
+                    // adjoint of (trim, / envelope): zero outside the kept region
+                    if (src >= 0 && src < n) {
+                        float g = xin[it];
+                        if ((unsigned)src == kmax) g -= adot * smax;
+                        g = g / (m * m2);
+                        v = g / (small_t ? ola_envelope_loop(a.plan.window2, p, T) : env[it]);
+                    } else {
+                        v = 0.f;
+                    }
+                }
+                chunk[i] = v;
             }
         }
-        chunk[i] = v;
     }
     __syncthreads();
 
@@ -401,15 +421,29 @@ __global__ __launch_bounds__(kThreads) void synth_kernel(SynthArgs a) {
     const int Ny = kHop * nblk;
     float* out = a.out + sig_offset(a.frame_off, b);
     const int j0 = kHop * jb0, j1 = kHop * jb1;
+    constexpr int NOUT = kSynthBlocks;              // (j1 - j0) / 256 <= 13 passes; loads batched ahead of their use
+    const bool small_t = T < 4;
     if (MODE == SY_FWD) {
         const float* add = a.add ? a.add + sig_offset(a.frame_off, b) : nullptr;
         unsigned long long best = 0;
-        for (int j = j0 + tid; j < j1; j += kThreads) {
-            const int p = kHalf + j;
-            float v = ola[p - pbase] / ola_envelope(a.plan, p, T);
-            if (add) v += add[j];
-            out[j] = v;
-            best = umax64(best, pack_max(fabsf(v), (unsigned)j));
+        float addv[NOUT], envv[NOUT];
+#pragma unroll
+        for (int it = 0; it < NOUT; ++it) {
+            const int j = j0 + tid + kThreads * it;
+            const int jc = j < j1 ? j : j0;
+            envv[it] = small_t ? 1.f : a.plan.env_tab[ola_envelope_index(kHalf + jc, T)];
+            addv[it] = add ? add[jc] : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < NOUT; ++it) {
+            const int j = j0 + tid + kThreads * it;
+            if (j < j1) {
+                const int p = kHalf + j;
+                float v = ola[p - pbase] / (small_t ? ola_envelope_loop(a.plan.window2, p, T) : envv[it]);
+                if (add) v += addv[it];
+                out[j] = v;
+                best = umax64(best, pack_max(fabsf(v), (unsigned)j));
+            }
         }
         if (a.pmax) {
             best = wave_max64(best);
@@ -422,13 +456,23 @@ __global__ __launch_bounds__(kThreads) void synth_kernel(SynthArgs a) {
         // dot product with the normalised forward signal for the normaliser's backward
         const float* y = a.yraw + sig_offset(a.frame_off, b);
         double acc = 0.0;
-        for (int j = j0 + tid; j < j1; j += kThreads) {
-            float g = ola[kHalf + j - pbase];
-            if (j >= 1 && j <= kHalf) g += ola[kHalf - j - pbase];
-            if (j >= Ny - kHalf - 1 && j <= Ny - 2) g += ola[2 * Ny + kHalf - 2 - j - pbase];
-            out[j] = g;
-            float y2 = (y[j] / cn.m) / cn.m2;
-            acc += (double)g * (double)y2;
+        float yv[NOUT];
+#pragma unroll
+        for (int it = 0; it < NOUT; ++it) {
+            const int j = j0 + tid + kThreads * it;
+            yv[it] = y[j < j1 ? j : j0];
+        }
+#pragma unroll
+        for (int it = 0; it < NOUT; ++it) {
+            const int j = j0 + tid + kThreads * it;
+            if (j < j1) {
+                float g = ola[kHalf + j - pbase];
+                if (j >= 1 && j <= kHalf) g += ola[kHalf - j - pbase];
+                if (j >= Ny - kHalf - 1 && j <= Ny - 2) g += ola[2 * Ny + kHalf - 2 - j - pbase];
+                out[j] = g;
+                float y2 = (yv[it] / cn.m) / cn.m2;
+                acc += (double)g * (double)y2;
+            }
         }
         acc = wave_sum_d(acc);
         if (lane == 0) dred[wave] = acc;

@@ -317,54 +317,72 @@ __global__ __launch_bounds__(64 * NW) void gemm_clip_x3_kernel(const float* __re
         // acc[m][0][e] holds this block's output (zero in padding rows).  The next conv block is the skinny last one
         // (CL <= 64 channels): its K = this N is split over the column slabs, so this workgroup contributes the partial
         // z_part[slab] = out[:, slab] * Wlast[:, slab]^T.  The output tile is re-laid as A fragments (k = column) in LDS.
+        // Work split: wave w takes K32 step t = w>>1 of the slab's 128 columns and half mh = w&1 of the row tiles (all
+        // column tiles of the last conv, CL <= 48); the four t-partials are then summed through LDS.
+        const int slab = bn >> 7, KS2L = N >> 5, ncl = (CL + 15) >> 4;
+        const int tq = wave >> 1, mh = wave & 1;
+        bf16x8 bl[3][3];
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+            if (n < ncl) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    bl[n][p] = __builtin_bit_cast(bf16x8, Lpk[(((size_t)n * KS2L + 4 * slab + tq) * 3 + p) * 64 + lane]);
+            }
         __syncthreads();                                  // every wave is done with the staging buffers
-        {
-            const int k = 16 * wave + r16;
-            unsigned char* d0 = lds + (size_t)((k >> 5) * 3 * MT) * FRAG + (16 * ((k & 31) >> 3)) * 16 + (k & 7) * 2;
+        // the output tile goes through LDS as f32 [row][column], row pitch 132 floats (conflict-free 4-byte stores from
+        // the accumulator layout); each wave reads its A fragments back as 8 consecutive columns per lane and splits them
+        float* const T = reinterpret_cast<float*>(lds);
+        constexpr int TP = 132;
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    unsigned p0, p1, p2;
-                    split_pair(acc[m][0][e], 0.f, p0, p1, p2);
-                    unsigned char* d = d0 + m * FRAG + (4 * kg + e) * 16;
-                    *reinterpret_cast<unsigned short*>(d) = (unsigned short)p0;
-                    *reinterpret_cast<unsigned short*>(d + MT * FRAG) = (unsigned short)p1;
-                    *reinterpret_cast<unsigned short*>(d + 2 * MT * FRAG) = (unsigned short)p2;
-                }
+            for (int e = 0; e < 4; ++e) T[(16 * m + 4 * kg + e) * TP + 16 * wave + r16] = acc[m][0][e];
+        __syncthreads();
+        f32x4 zt[MH][3];
+#pragma unroll
+        for (int mm = 0; mm < MH; ++mm) {
+#pragma unroll
+            for (int n = 0; n < 3; ++n) zt[mm][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* src = T + (16 * (mh * MH + mm) + r16) * TP + 32 * tq + 8 * kg;
+            const float4 x0 = *reinterpret_cast<const float4*>(src), x1 = *reinterpret_cast<const float4*>(src + 4);
+            uint4 q0, q1, q2;
+            split_pair(x0.x, x0.y, q0.x, q1.x, q2.x);
+            split_pair(x0.z, x0.w, q0.y, q1.y, q2.y);
+            split_pair(x1.x, x1.y, q0.z, q1.z, q2.z);
+            split_pair(x1.z, x1.w, q0.w, q1.w, q2.w);
+            bf16x8 a[3];
+            a[0] = __builtin_bit_cast(bf16x8, q0); a[1] = __builtin_bit_cast(bf16x8, q1); a[2] = __builtin_bit_cast(bf16x8, q2);
+#pragma unroll
+            for (int term = 0; term < 6; ++term) {
+                const int pa = term == 0 ? 2 : (term == 1 || term == 3) ? 1 : 0;
+                const int pb = term == 2 ? 2 : (term == 1 || term == 4) ? 1 : 0;
+#pragma unroll
+                for (int n = 0; n < 3; ++n)
+                    if (n < ncl) zt[mm][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[pa], bl[n][pb], zt[mm][n], 0, 0, 0);
+            }
         }
+        __syncthreads();                                  // all fragment reads done: the buffer becomes the partial store
+#pragma unroll
+        for (int mm = 0; mm < MH; ++mm)
+#pragma unroll
+            for (int n = 0; n < 3; ++n)
+                *reinterpret_cast<f32x4*>(lds + (size_t)((wave * MH + mm) * 3 + n) * FRAG + lane * 16) = zt[mm][n];
         __syncthreads();
         if (wave < MT) {
-            const int slab = bn >> 7, KS2L = N >> 5, ncl = (CL + 15) >> 4;
-            f32x4 zt[4];
-#pragma unroll
-            for (int n = 0; n < 4; ++n) zt[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-            for (int t = 0; t < 4; ++t) {                 // not unrolled: keeps the kernel at 4 waves per SIMD
-                bf16x8 a[3];
-#pragma unroll
-                for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const bf16x8*>(lds + (size_t)((t * 3 + p) * MT + wave) * FRAG + lane * 16);
-#pragma unroll
-                for (int n = 0; n < 4; ++n)
-                    if (n < ncl) {
-                        bf16x8 b[3];
-#pragma unroll
-                        for (int p = 0; p < 3; ++p)
-                            b[p] = __builtin_bit_cast(bf16x8, Lpk[(((size_t)n * KS2L + 4 * slab + t) * 3 + p) * 64 + lane]);
-                        zt[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], zt[n], 0, 0, 0);
-                        zt[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], zt[n], 0, 0, 0);
-                        zt[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], zt[n], 0, 0, 0);
-                        zt[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], zt[n], 0, 0, 0);
-                        zt[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], zt[n], 0, 0, 0);
-                        zt[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], zt[n], 0, 0, 0);
-                    }
-            }
+            const int smh = wave / MH, smm = wave % MH;   // this wave finishes row tile `wave`
             float* zp = zpart + (size_t)slab * ((size_t)(ntiles / tiles_n) * 32 * RG * CL) + (size_t)(bm + 16 * wave + 4 * kg) * CL;
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
-                if (n < ncl && 16 * n + r16 < CL) {
+            for (int n = 0; n < 3; ++n)
+                if (n < ncl) {
+                    f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) zp[(size_t)e * CL + 16 * n + r16] = zt[n][e];
+                    for (int q = 0; q < 4; ++q)
+                        t += *reinterpret_cast<const f32x4*>(lds + (size_t)(((2 * q + smh) * MH + smm) * 3 + n) * FRAG + lane * 16);
+                    if (16 * n + r16 < CL) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) zp[(size_t)e * CL + 16 * n + r16] = t[e];
+                    }
                 }
         }
     }
@@ -665,7 +683,7 @@ __global__ __launch_bounds__(512) void readout_x3_kernel(const float* __restrict
     STAMP(5);
 }
 
-bool readout_x3_supported(int nwm, int ci, int C) { return nwm >= 1 && nwm <= 4 && ci % 256 == 0 && C >= 2 && C <= 64 && C % 2 == 0; }
+bool readout_x3_supported(int nwm, int ci, int C) { return nwm >= 1 && nwm <= 4 && ci % 256 == 0 && C >= 2 && C <= 48 && C % 2 == 0; }
 
 // zpart: [nslab][B*32*nwm][C] split-K partials of the last conv (written by launch_gemm_clip_x3 with lastpk/zpart);
 // WTpk: x3_pack of the last conv's transposed weights ([ci][C], k zero-padded to 64)

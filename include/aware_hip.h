@@ -51,7 +51,9 @@ const char* aware_last_hip_error(void);
  * 4 [default]: bf16 matrix pipe, operands split exactly into three bf16 terms, six partial products per
  * multiply-add, f32 accumulation (f32-equivalent accuracy; csrc/gemm_x3.hip) for K % 64 == 0, N % 128 == 0,
  * f32 MFMA otherwise.  0..3: f32 MFMA everywhere (0: BK 32 x1, 1: BK 64 x1, 2: BK 32 x2, 3: direct-to-LDS
- * loads x2; identical results among 0..3). */
+ * loads x2; identical results among 0..3).
+ * key 2 = fused read-out kernel of the embed loop on uniform batches (1 [default] / 0: split-K GEMM + tail kernel +
+ * data-gradient GEMM, the path ragged batches always take). */
 int aware_tune(int key, int value);
 
 /* ---- plan: FFT twiddles, window, band ------------------------------------------------
