@@ -918,19 +918,25 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_reg_kernel(float* __restrict
     const int cl = threadIdx.x & 63, g = threadIdx.x >> 6, c = c0 + cl;
     if (Tp <= 0) return;
     const bool ok = c < C;
-    float* d = dA + (size_t)r0 * C + c;
-    const float* a = A + (size_t)r0 * C + c;
+    const int cc = ok ? c : C - 1;
+    float* d = dA + (size_t)r0 * C + cc;
+    const float* a = A + (size_t)r0 * C + cc;
     float du[R], u[R];
     float p1 = 0.f, p2 = 0.f;
+    // loads from clamped indices, masked afterwards: a load inside a per-row branch waits for its own latency
 #pragma unroll
     for (int i = 0; i < R; ++i) {
         const int t = g + 4 * i;
-        du[i] = 0.f; u[i] = 0.f;
-        if (ok && t < Tp) {
-            const float av = a[(size_t)t * C];
-            u[i] = av > 0.f ? av : av * 5.0f;            // invert LeakyReLU(0.2)
-            du[i] = d[(size_t)t * C] * (av > 0.f ? 1.f : 0.2f);
-        }
+        const int tc = t < Tp ? t : Tp - 1;
+        u[i] = a[(size_t)tc * C];
+        du[i] = d[(size_t)tc * C];
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const bool valid = ok && g + 4 * i < Tp;
+        const float av = u[i];
+        u[i] = valid ? (av > 0.f ? av : av * 5.0f) : 0.f;            // invert LeakyReLU(0.2)
+        du[i] = valid ? du[i] * (av > 0.f ? 1.f : 0.2f) : 0.f;
         p1 += du[i]; p2 += du[i] * u[i];
     }
     s1[g][cl] = p1; s2[g][cl] = p2;
@@ -1079,17 +1085,17 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ zpa
 #pragma unroll
     for (int i = 0; i < R; ++i) {
         const int t = g + 4 * i;
-        z[i] = 0.f;
-        if (ok && t < Tp) {
-            float part[NSPLIT];
+        // clamped index + mask instead of a branch around the loads (they would wait one by one)
+        const int tc = t < Tp ? t : Tp - 1;
+        const int cc = ok ? c : C - 1;
+        float part[NSPLIT];
 #pragma unroll
-            for (int k = 0; k < NSPLIT; ++k) part[k] = zpart[k * slab + (size_t)(r0 + t) * C + c];
-            float acc = bv;
+        for (int k = 0; k < NSPLIT; ++k) part[k] = zpart[k * slab + (size_t)(r0 + tc) * C + cc];
+        float acc = bv;
 #pragma unroll
-            for (int k = 0; k < NSPLIT; ++k) acc += part[k];
-            z[i] = acc;
-            s += acc;
-        }
+        for (int k = 0; k < NSPLIT; ++k) acc += part[k];
+        z[i] = (ok && t < Tp) ? acc : 0.f;
+        s += z[i];
     }
     red[g][c] = s;
     __syncthreads();
