@@ -756,10 +756,24 @@ __global__ __launch_bounds__(256) void mel_apply_pool_kernel(const float* __rest
     const float* x = xm + (size_t)f0 * 128 + c;
     float* o = x0 + (size_t)pool_off[b] * 128 + c;
     const int tp0 = t0 / 2, tp1 = min(Tp, tp0 + kMelChunk / 2);
-    for (int tp = tp0 + g; tp < tp1; tp += 2) {
-        float u0 = (x[(size_t)(2 * tp) * 128] - mu) * rs;
-        float u1 = (x[(size_t)(2 * tp + 1) * 128] - mu) * rs;
-        o[(size_t)tp * 128] = 0.5f * (u0 * ginv + u1 * ginv);
+    if (Tp > 0) {
+        // fixed trip count, loads first (clamped indices), stores masked: no per-iteration load/wait chain
+        constexpr int NI = kMelChunk / 4;
+        float xa[NI], xb[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int tc = min(tp0 + g + 2 * i, Tp - 1);
+            xa[i] = x[(size_t)(2 * tc) * 128];
+            xb[i] = x[(size_t)(2 * tc + 1) * 128];
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int tp = tp0 + g + 2 * i;
+            if (tp < tp1) {
+                const float u0 = (xa[i] - mu) * rs, u1 = (xb[i] - mu) * rs;
+                o[(size_t)tp * 128] = 0.5f * (u0 * ginv + u1 * ginv);
+            }
+        }
     }
     // pooled rows are 32-aligned per clip: keep the pad rows finite (they flow through the GEMMs)
     if ((int)blockIdx.x == nchunk - 1)
@@ -783,11 +797,24 @@ __global__ __launch_bounds__(256) void mel_bwd_partial_kernel(const float* __res
     const float* d0 = dx0 + (size_t)pool_off[b] * 128 + c;
     const int tp0 = t0 / 2, tp1 = min(Tp, tp0 + kMelChunk / 2);
     float a1 = 0.f, a2 = 0.f;
-    for (int tp = tp0 + g; tp < tp1; tp += 2) {
-        const float dv = 0.5f * d0[(size_t)tp * 128];
-        const float u0 = (x[(size_t)(2 * tp) * 128] - mu) * rs, u1 = (x[(size_t)(2 * tp + 1) * 128] - mu) * rs;
-        a1 += 2.f * dv;
-        a2 += dv * u0 + dv * u1;
+    if (Tp > 0) {
+        constexpr int NI = kMelChunk / 4;
+        float dd[NI], xa[NI], xb[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int tc = min(tp0 + g + 2 * i, Tp - 1);
+            dd[i] = d0[(size_t)tc * 128];
+            xa[i] = x[(size_t)(2 * tc) * 128];
+            xb[i] = x[(size_t)(2 * tc + 1) * 128];
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            if (tp0 + g + 2 * i < tp1) {
+                const float dv = 0.5f * dd[i];
+                const float u0 = (xa[i] - mu) * rs, u1 = (xb[i] - mu) * rs;
+                a1 += 2.f * dv;
+                a2 += dv * u0 + dv * u1;
+            }
     }
     s1[g][c] = a1; s2[g][c] = a2;
     __syncthreads();
@@ -825,11 +852,25 @@ __global__ __launch_bounds__(256) void mel_bwd_apply_kernel(const float* __restr
     float* x = xm + (size_t)f0 * 128 + c;
     const float* d0 = dx0 + (size_t)pool_off[b] * 128 + c;
     const int t1 = min(T, t0 + kMelChunk);
-    for (int t = t0 + g; t < t1; t += 2) {
-        const float dv = (t < 2 * Tp) ? 0.5f * d0[(size_t)(t >> 1) * 128] : 0.f;
-        const float u = (x[(size_t)t * 128] - mu) * rs;
-        const float du = (dv - mdv) * ginv - u * Q;
-        x[(size_t)t * 128] = rs * (du - m1 - u * m2);
+    {
+        constexpr int NI = kMelChunk / 2;
+        float dd[NI], xv[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int tc = min(t0 + g + 2 * i, T - 1);
+            dd[i] = d0[(size_t)min(tc >> 1, max(Tp - 1, 0)) * 128];
+            xv[i] = x[(size_t)tc * 128];
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int t = t0 + g + 2 * i;
+            if (t < t1) {
+                const float dv = (t < 2 * Tp) ? 0.5f * dd[i] : 0.f;
+                const float u = (xv[i] - mu) * rs;
+                const float du = (dv - mdv) * ginv - u * Q;
+                x[(size_t)t * 128] = rs * (du - m1 - u * m2);
+            }
+        }
     }
 }
 
