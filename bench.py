@@ -71,9 +71,8 @@ def cpu_baseline(seconds_budget=20.0):
 
 
 def pmc_traffic_per_launch(per_gpu):
-    """Mean HBM bytes per gemm_clip launch from the committed PMC passes (profiles/, same kernels and
-    batch; bench.py cannot collect PMC counters itself).  Rows are medians per (kernel, grid); the
-    larger grid of each epilogue kind is launched twice per iteration, the smaller once.
+    """Mean HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/, same kernels and
+    batch; bench.py cannot collect PMC counters itself).  One row of the profile = one launch per iteration.
     Returns (bytes, source) or (None, None) when no profile of this batch size is present."""
     import csv
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic_pmc.csv")
@@ -81,12 +80,10 @@ def pmc_traffic_per_launch(per_gpu):
         return None, None
     with open(path) as f:
         rows = [r for r in csv.reader(l for l in f if not l.startswith("#"))][1:]
-    sel = [(int(r[2]), float(r[3]) + float(r[4])) for r in rows if int(r[0]) == per_gpu and "gemm_clip_kernel" in r[1]]
-    if len(sel) != 4:
+    sel = [float(r[3]) + float(r[4]) for r in rows if int(r[0]) == per_gpu and "gemm_clip_x3_kernel<3," in r[1]]
+    if len(sel) != 5:
         return None, None
-    big = max(g for g, _ in sel)
-    tot = sum(mb * (2 if g == big else 1) for g, mb in sel)
-    return tot / 6.0 * 1048576.0, "profiles/r01_hbm_traffic_pmc.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 fetch x2 correction)"
+    return sum(sel) / len(sel) * 1048576.0, "profiles/r01_hbm_traffic_pmc.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 fetch x2 correction)"
 
 
 def log(*a):
@@ -172,13 +169,13 @@ def main():
         if "gemm_x3_fwd" in breakdown:
             # dominant kernel: the clip-aligned conv block on the bf16 matrix pipe (gemm_x3.hip), 5 launches per
             # iteration: conv0..2 forward (K = 128, 512, 1024) and the data gradients of conv2, conv1 (K = 1024);
-            # the K = 40 data gradient of conv3 stays on the f32-MFMA kernel and is not counted here
+            # (the skinny last conv and its data gradient live in the forward epilogue and in readout_x3_kernel)
             fl = 2.0 * rows * (ch[0] * ch[1] + ch[1] * ch[2] + ch[2] * ch[3]) + 2.0 * rows * (ch[3] * ch[2] + ch[2] * ch[1])
             ms = breakdown["gemm_x3_fwd"][0] + breakdown["gemm_x3_bwd"][0]
             nl = breakdown["gemm_x3_fwd"][1] + breakdown["gemm_x3_bwd"][1]
-            name = "aware::gemm_clip_x3_kernel<3,EPI> (EPI=1 forward x3, EPI=2 backward x2 per iteration)"
-            per_kernel = {"gemm_clip_x3_kernel<3,1>": round(breakdown["gemm_x3_fwd"][0] * 1e3 / breakdown["gemm_x3_fwd"][1], 2),
-                          "gemm_clip_x3_kernel<3,2>": round(breakdown["gemm_x3_bwd"][0] * 1e3 / breakdown["gemm_x3_bwd"][1], 2)}
+            name = "aware::gemm_clip_x3_kernel<3,EPI,8> (forward EPI=1 x2 and EPI=3 x1, backward EPI=2 x2 per iteration)"
+            per_kernel = {"gemm_clip_x3_kernel<3,1|3,8>": round(breakdown["gemm_x3_fwd"][0] * 1e3 / breakdown["gemm_x3_fwd"][1], 2),
+                          "gemm_clip_x3_kernel<3,2,8>": round(breakdown["gemm_x3_bwd"][0] * 1e3 / breakdown["gemm_x3_bwd"][1], 2)}
             peak = MFMA_BF16_PEAK_TF / 6.0
             peak_note = ("f32-equivalent peak of this kernel: dense bf16 MFMA peak (2.5 PFLOP/s) / 6 bf16 partial products per "
                          "f32 multiply-add")
@@ -210,15 +207,15 @@ def main():
                             "unit": "GB/s", "frac": round(dsp_bytes / (dsp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                             "avg_launch_us": round(dsp_ms * 1e3 / (4 * n_it), 2)}}
 
-        if "gemm_x3_fwd" not in breakdown and "gemm_clip_fwd" in breakdown and len(set(batch.frames)) == 1:
+        if "gemm_x3_fwd" in breakdown and len(set(batch.frames)) == 1:
             tb, src = pmc_traffic_per_launch(len(batch.frames))
             if tb is not None:
                 roof["traffic"], roof["traffic_source"] = round(tb), src
-                # operands of one launch: A rows + output rows + weights
-                alg = 4.0 * (rows * (ch[0] + ch[1]) + rows * (ch[1] + ch[2]) + rows * (ch[2] + ch[3])
-                             + rows * (ch[4] + ch[3]) + rows * (ch[3] + ch[2]) + rows * (ch[2] + ch[1])
-                             + 2 * (ch[0] * ch[1] + ch[1] * ch[2] + ch[2] * ch[3]) + ch[3] * ch[4])
-                roof["algorithmic_bytes_per_launch"] = round(alg / 6)
+                # operands of the five launches: A rows (f32) + output rows (f32) + packed weights (3 x bf16), and the
+                # forward activation re-read by the two backward epilogues
+                pairs = [(ch[0], ch[1]), (ch[1], ch[2]), (ch[2], ch[3]), (ch[3], ch[2]), (ch[2], ch[1])]
+                alg = sum(4.0 * rows * (k + n) + 6.0 * k * n for k, n in pairs) + 4.0 * rows * (ch[2] + ch[1])
+                roof["algorithmic_bytes_per_launch"] = round(alg / 5)
     if world > 1:
         import torch.distributed as dist
         parallel.barrier()
