@@ -329,4 +329,45 @@ void launch_spectral_quantize(void* spec, int nframes, float step_db, float floo
     hipLaunchKernelGGL(spectral_quantize_kernel, dim3((nframes + 3) / 4), dim3(256), 0, st, (cf*)spec, nframes, step_db,
                        floor_db);
 }
+
+// ---------------------------------------------------------------------------------
+// SNR in dB of `a` (output) against `b` (target) per clip over len[c] samples:
+// 10 log10(mean(a^2) / mean((a-b)^2)), +inf when identical  (metrics/audio.py:68-89)
+// One workgroup per clip, f64 accumulation in a fixed order (deterministic).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void snr_kernel(const float* __restrict__ a, const int* __restrict__ a_off,
+                                                   const float* __restrict__ b, const int* __restrict__ b_off,
+                                                   const int* __restrict__ len, double* __restrict__ out) {
+    __shared__ double r1[4], r2[4];
+    const int c = blockIdx.x, n = len[c];
+    const float* x = a + a_off[c];
+    const float* y = b + b_off[c];
+    double s1 = 0.0, s2 = 0.0;
+    for (int i0 = 0; i0 < n; i0 += 256 * 8) {
+        float xv[8], yv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {                       // loads first (clamped), then use
+            const int i = min(i0 + threadIdx.x + 256 * u, n - 1);
+            xv[u] = x[i]; yv[u] = y[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + (int)threadIdx.x + 256 * u < n) {
+                const double p = (double)xv[u], d = (double)xv[u] - (double)yv[u];
+                s1 += p * p; s2 += d * d;
+            }
+    }
+    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+    if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = s1; r2[threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double p = (r1[0] + r1[1]) + (r1[2] + r1[3]), d = (r2[0] + r2[1]) + (r2[2] + r2[3]);
+        out[c] = (d == 0.0) ? (double)INFINITY : 10.0 * log10(p / d);
+    }
+}
+void launch_snr(const float* a, const int* a_off, const float* b, const int* b_off, const int* len, double* out, int B,
+                hipStream_t st) {
+    hipLaunchKernelGGL(snr_kernel, dim3(B), dim3(256), 0, st, a, a_off, b, b_off, len, out);
+}
+
 }  // namespace aware

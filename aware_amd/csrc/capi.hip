@@ -1001,6 +1001,14 @@ extern "C" int aware_gaussian_noise(const float* in, float* out, const int* off,
     return AWARE_OK;
 }
 
+extern "C" int aware_snr(const float* output, const int* out_offsets, const float* target, const int* tgt_offsets,
+                         const int* lengths, int B, double* snr_db, void* stream) {
+    if (!output || !out_offsets || !target || !tgt_offsets || !lengths || !snr_db || B < 1) return AWARE_E_BADARG;
+    launch_snr(output, out_offsets, target, tgt_offsets, lengths, snr_db, B, (hipStream_t)stream);
+    LAUNCHCHK();
+    return AWARE_OK;
+}
+
 extern "C" int aware_spectral_quantize(void* spec, int n_frames, float step_db, float floor_db, void* stream) {
     if (!spec || n_frames < 1 || !(step_db > 0.f)) return AWARE_E_BADARG;
     launch_spectral_quantize(spec, n_frames, step_db, floor_db, (hipStream_t)stream);

@@ -200,11 +200,15 @@ __global__ __launch_bounds__(64 * NW) void gemm_clip_x3_kernel(const float* __re
 #pragma unroll
         for (int q = 0; q < 4; ++q) {                 // quarter = (K32 step q>>1, row half q&1)
             const int t = q >> 1, hf = q & 1;
+#if !(X3_ABLATE & 1)
             if (hf == 0) loadB((t + 1) & 1, kt * 2 + t + 1);          // B fragments one K32 step ahead
+#endif
+#if !(X3_ABLATE & 2)
             if (q < NCH) {
                 split_store_c(q, nxt);
                 gload_c(q, ktn);
             }
+#endif
             if (q < 3) {
                 read_frags((q + 1) & 1, cur + rb[(q + 1) >> 1] + ((q + 1) & 1) * MH * FRAG);
             } else {

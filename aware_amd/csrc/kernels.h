@@ -130,6 +130,8 @@ void launch_iir_full(const float* in, const int* off, const int* len, void* out,
                      hipStream_t st);
 void launch_gaussian_noise_full(const float* in, float* out, const int* off, const int* len, const unsigned* seeds,
                                 double* power, float snr_db, int B, int max_len, hipStream_t st);
+void launch_snr(const float* a, const int* a_off, const float* b, const int* b_off, const int* len, double* out, int B,
+                hipStream_t st);
 void launch_spectral_quantize(void* spec, int nframes, float step_db, float floor_db, hipStream_t st);
 void launch_segment_copy(const float* in, const int* in_off, float* out, const int* out_off, const int* out_len,
                          const int* cut_start, const int* cut_len, int zero_fill, int B, int max_len, hipStream_t st);

@@ -1,3 +1,3 @@
-from .audio import BER, SNR
+from .audio import BER, SNR, snr_batch
 
-__all__ = ["BER", "SNR"]
+__all__ = ["BER", "SNR", "snr_batch"]

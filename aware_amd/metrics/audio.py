@@ -25,3 +25,9 @@ class SNR(BaseMetrics):
         if np.all(o == t):
             return float("inf")
         return float(10 * np.log10(np.mean(o ** 2) / np.mean((o - t) ** 2)))
+
+
+def snr_batch(output, target):
+    """SNR of every clip of two ragged device batches (aware_amd.runtime.Ragged), on the GPU: float64 tensor [B]."""
+    from .. import runtime as rt
+    return rt.snr_db(output, target)

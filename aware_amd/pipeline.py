@@ -23,6 +23,8 @@ class PipelineResult:
     watermarked: "rt.Ragged" = None
     per_attack_errors: dict = field(default_factory=dict)
     seconds: float = 0.0                  # waveform-seconds processed (at the input rate)
+    snr_db: torch.Tensor = None           # [B] float64: watermarked vs host clip at 16 kHz (report_snr=True)
+    watermarked_out: "rt.Ragged" = None   # watermarked clips converted to `output_rate` (when requested)
 
 
 class WatermarkPipeline:
@@ -34,6 +36,7 @@ class WatermarkPipeline:
         self.sample_rate = sample_rate
         self.attack_mode = attack_mode
         self._sessions = {}
+        self._host16k = None
 
     def prepare(self, lengths_16k, input_rate: int | None = None):
         """One-time set-up for a batch geometry (lengths at the pipeline's 16 kHz): geometry tables,
@@ -69,7 +72,20 @@ class WatermarkPipeline:
         return (vals > self.detector.threshold).to(torch.int32), vals
 
     def run(self, audio: "rt.Ragged", bits: torch.Tensor, input_rate: int | None = None, chains=None,
-            chain_of_clip=None) -> PipelineResult:
+            chain_of_clip=None, report_snr: bool = False, output_rate: int | None = None) -> PipelineResult:
+        res = self._run(audio, bits, input_rate, chains, chain_of_clip)
+        if report_snr:
+            # imperceptibility metric of the reference (metrics/audio.py:68-89) on the device: watermarked clip
+            # against the 16 kHz host clip over their common length
+            res.snr_db = rt.snr_db(res.watermarked, self._host16k)
+        if output_rate and output_rate != self.sample_rate:
+            # back end of the 44.1 kHz flow (README.md:26-37 of the reference): polyphase 16 kHz -> output_rate
+            res.watermarked_out = resample_poly_batch(res.watermarked, output_rate, self.sample_rate)
+        self._host16k = None
+        return res
+
+    def _run(self, audio: "rt.Ragged", bits: torch.Tensor, input_rate: int | None = None, chains=None,
+             chain_of_clip=None) -> PipelineResult:
         """audio: ragged device clips at `input_rate` (default: the pipeline's 16 kHz);
         bits: device int tensor [B, n_bits] of 0/1.
         chains / chain_of_clip (BASELINE config 5): `chains` is a list of attack lists and
@@ -80,6 +96,7 @@ class WatermarkPipeline:
         x = audio
         if input_rate != self.sample_rate:
             x = resample_poly_batch(audio, self.sample_rate, input_rate)            # scripts/test.py:60-63
+        self._host16k = x
         key = tuple(x.lengths)
         if key not in self._sessions:          # geometry tables + workspace are reused across steps
             b = rt.Batch(x.lengths)

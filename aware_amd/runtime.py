@@ -421,6 +421,20 @@ def gaussian_noise(x: Ragged, snr_db: float, seeds: Sequence[int]) -> Ragged:
     return out
 
 
+def snr_db(output: Ragged, target: Ragged) -> torch.Tensor:
+    """Per-clip SNR in dB of `output` against `target` over the common length (metrics/audio.py:68-89);
+    device float64 tensor [B]."""
+    if output.B != target.B:
+        raise ValueError("snr_db: batches differ in size")
+    lib = load_library()
+    dev = output.data.device
+    n = torch.minimum(output.d_len, target.d_len)
+    out = torch.empty(output.B, dtype=torch.float64, device=dev)
+    check(lib.aware_snr(_ptr(output.data), _ptr(output.d_off), _ptr(target.data), _ptr(target.d_off), _ptr(n), output.B,
+                        _ptr(out), _stream()), "aware_snr")
+    return out
+
+
 KERNEL_KINDS = ["synth", "analysis", "gemm_nt", "mel_norm", "in_lrelu", "readout_tail", "synth_adjoint",
                 "analysis_adjoint_nadam", "misc", "gemm_clip_fwd", "gemm_clip_bwd", "gemm_x3_fwd", "gemm_x3_bwd"]
 

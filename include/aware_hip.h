@@ -191,6 +191,13 @@ int aware_gaussian_noise(const float* in, float* out, const int* off, const int*
  * Used as  aware_stft -> aware_spectral_quantize -> aware_istft. */
 int aware_spectral_quantize(void* spec, int n_frames, float step_db, float floor_db, void* stream);
 
+/* ---- quality metric ----------------------------------------------------------------------------------
+ * SNR.__call__ (src/AWARE/metrics/audio.py:68-89) per clip: 10 log10(mean(output^2) / mean((output - target)^2))
+ * over lengths[c] samples (the caller passes the common length, :82-84), +inf when the clips are identical;
+ * f64 accumulation in a fixed order.  Offsets are float offsets of clip c in the two signal arrays. */
+int aware_snr(const float* output, const int* out_offsets, const float* target, const int* tgt_offsets,
+              const int* lengths, int B, double* snr_db, void* stream);
+
 /* ---- bare GEMM (tests / roofline): C[M][N] = A[M][K] * Bt[N][K]^T + bias ------------------------------ */
 int aware_gemm_nt(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc,
                   int M, int N, int K, void* stream);

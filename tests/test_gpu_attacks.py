@@ -118,3 +118,29 @@ def test_mp3_surrogate_extension(A):
     assert out.shape == ref.shape == (15872,)
     assert np.linalg.norm(out - ref) / np.linalg.norm(ref) < 2e-3
     assert 0.5 < np.linalg.norm(out) / np.linalg.norm(a[:15872]) < 1.5
+
+
+def test_snr_on_gpu(A):
+    from aware_amd import runtime as rt
+    """aware_snr against the reference formula (metrics/audio.py:68-89) evaluated in float64 on the host,
+    ragged clips, different lengths in the two batches (common length is used), identical clips -> +inf."""
+    rng = np.random.default_rng(5)
+    la, lb = [48000, 1000, 16001, 7], [47872, 1200, 16001, 7]
+    a = [rng.standard_normal(n).astype(np.float32) * 0.1 for n in la]
+    b = [x[:m].copy() if m <= len(x) else np.concatenate([x, np.zeros(m - len(x), np.float32)]) for x, m in zip(a, lb)]
+    for i in (0, 1, 2):
+        b[i] = (b[i] + rng.standard_normal(len(b[i])).astype(np.float32) * 10.0 ** (-i - 1)).astype(np.float32)
+    ra = rt.Ragged(torch.from_numpy(np.concatenate(a)).cuda(), la)
+    rb = rt.Ragged(torch.from_numpy(np.concatenate(b)).cuda(), lb)
+    got = rt.snr_db(ra, rb).cpu().numpy()
+    for i in range(4):
+        n = min(la[i], lb[i])
+        o, t = a[i][:n].astype(np.float64), b[i][:n].astype(np.float64)
+        ref = np.inf if np.all(o == t) else 10 * np.log10(np.mean(o ** 2) / np.mean((o - t) ** 2))
+        if np.isinf(ref):
+            assert np.isinf(got[i]) and got[i] > 0
+        else:
+            assert abs(got[i] - ref) < 1e-9, (i, got[i], ref)
+    # and against the host metric class (float32 numpy arithmetic like the reference)
+    from aware_amd.metrics import SNR
+    assert abs(SNR()(a[0], b[0]) - got[0]) < 1e-3

@@ -279,3 +279,41 @@ def test_degenerate_inputs_stay_finite(models):
     o = batch.unpack_out(out)
     assert float(o[0].abs().max()) == 0.0                 # silence stays silence
     assert [x.numel() for x in o] == [15872, 512, 15872]
+
+
+def test_pipeline_snr_and_44k_back_end(models):
+    """the imperceptibility metric on the device and the 16 kHz -> 44.1 kHz back end.
+    SNR: the +-6 dB box around every band magnitude bounds the distortion, so the watermarked clip stays within a
+    few dB of the host (the oracle's own embed of the 1 s golden clip gives the reference value);
+    back end: polyphase 441/160 of the watermarked clip = scipy.signal.resample_poly on the same samples."""
+    from scipy.signal import resample_poly
+    from aware_amd import runtime as rt
+    from aware_amd.pipeline import WatermarkPipeline
+    from oracle import aware_oracle as O
+    emb, det = models
+    clips = [make_clip(s, n) for s, n in zip((1, 7), (16000, 20000))]
+    audio = rt.Ragged(torch.from_numpy(np.concatenate([c[0] for c in clips])).cuda(), [16000, 20000])
+    bits = torch.from_numpy(np.stack([c[1] for c in clips])).cuda()
+    pipe = WatermarkPipeline(emb, det)
+    res = pipe.run(audio, bits, report_snr=True, output_rate=44100)
+    assert int(res.bit_errors) == 0
+    snr = res.snr_db.cpu().numpy()
+    wm = res.watermarked
+    for i, (a, _) in enumerate(clips):
+        w = wm.data[wm.offsets[i]: wm.offsets[i] + wm.lengths[i]].cpu().numpy()
+        n = min(len(w), len(a))
+        ref = 10 * np.log10(np.mean(w[:n].astype(np.float64) ** 2) / np.mean((w[:n].astype(np.float64) - a[:n]) ** 2))
+        assert abs(snr[i] - ref) < 1e-6
+        assert 0.0 < snr[i] < 40.0
+        up = res.watermarked_out
+        got = up.data[up.offsets[i]: up.offsets[i] + up.lengths[i]].cpu().numpy()
+        want = resample_poly(w.astype(np.float32), 441, 160)
+        assert got.shape == want.shape
+        assert np.max(np.abs(got - want)) < 3e-6 * max(1.0, np.max(np.abs(want)))
+    # the oracle's embed of the golden 1 s clip lands at the same SNR (both trajectories stay in the same box)
+    e = np.load(os.path.join(GOLDEN, "embed_1s.npz"))
+    ref_out = e["out_sample"]
+    a = clips[0][0]
+    n = min(len(ref_out), len(a))
+    ref_snr = 10 * np.log10(np.mean(ref_out[:n].astype(np.float64) ** 2) / np.mean((ref_out[:n].astype(np.float64) - a[:n]) ** 2))
+    assert abs(snr[0] - ref_snr) < 1.0, (snr[0], ref_snr)
