@@ -20,6 +20,18 @@
 
 namespace aware {
 
+// 1-ulp hardware reciprocal / square root (v_rcp_f32, v_sqrt_f32) instead of the ~10-instruction IEEE expansions
+// hipcc emits for `/` and sqrtf: a quarter of the analysis kernels' vector instructions were division fix-ups.
+// Where the reference divides by a per-clip scalar (waveform.py:18-19) the scalar's reciprocal is still an IEEE
+// division, taken once per thread; the per-sample operation becomes a multiplication (<= 1 ulp from the quotient).
+#ifndef AWARE_EXACT_DIV
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+#else
+__device__ __forceinline__ float fast_rcp(float x) { return 1.0f / x; }
+__device__ __forceinline__ float fast_sqrt(float x) { return sqrtf(x); }
+#endif
+
 // ---------------------------------------------------------------------------------
 // |x| maximum per clip, as per-segment partials (4096 samples per workgroup)
 // ---------------------------------------------------------------------------------
@@ -128,6 +140,7 @@ __global__ __launch_bounds__(kThreads) void analysis_kernel(AnalysisArgs a) {
         // would wait for its own latency 19 times over)
         constexpr int NIT = kChunk / kThreads;
         const bool small_t = T < 4;                    // clips shorter than the envelope tables assume
+        const float inv_m = 1.0f / m, inv_m2 = 1.0f / m2, inv_mm2 = 1.0f / (m * m2);
         float xin[NIT], env[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -149,14 +162,14 @@ __global__ __launch_bounds__(kThreads) void analysis_kernel(AnalysisArgs a) {
                 float v;
                 if (MODE == AN_NORM) {
                     v = xin[it];
-                    if (a.pmax) { v = v / m; if (a.double_norm) v = v / m2; }
+                    if (a.pmax) { v = v * inv_m; if (a.double_norm) v = v * inv_m2; }
                 } else {
                     // adjoint of (trim, / envelope): zero outside the kept region
                     if (src >= 0 && src < n) {
                         float g = xin[it];
                         if ((unsigned)src == kmax) g -= adot * smax;
-                        g = g / (m * m2);
-                        v = g / (small_t ? ola_envelope_loop(a.plan.window2, p, T) : env[it]);
+                        g = g * inv_mm2;
+                        v = g * fast_rcp(small_t ? ola_envelope_loop(a.plan.window2, p, T) : env[it]);
                     } else {
                         v = 0.f;
                     }
@@ -180,9 +193,11 @@ __global__ __launch_bounds__(kThreads) void analysis_kernel(AnalysisArgs a) {
     }
     const int band_lo = a.plan.band_lo, nband = a.plan.nband;
     float4 sc = make_float4(0.f, 0.f, 1.f, 0.f);
+    float inv_bc2 = 1.f;
     int improved = 0;
     if (MODE == AN_ADJ && a.do_step) {
         sc = a.sched[*a.step - 1];      // the read-out kernel of this iteration already advanced the counter
+        inv_bc2 = 1.0f / sc.z;
         improved = a.improved[b];
     }
 
@@ -240,9 +255,10 @@ __global__ __launch_bounds__(kThreads) void analysis_kernel(AnalysisArgs a) {
                 }
                 cf X = rfft_split_bin(k, v[r], s, a.plan.tw1024);
                 if (MODE == AN_NORM) {
-                    float mg = sqrtf(X.x * X.x + X.y * X.y);
+                    const float mg = fast_sqrt(X.x * X.x + X.y * X.y);
+                    const float im = fast_rcp(mg);
                     if (a.mag) a.mag[idx] = mg;
-                    if (a.unit) a.unit[idx] = (mg > 0.f) ? mk(X.x / mg, X.y / mg) : mk(a.unit_default, 0.f);
+                    if (a.unit) a.unit[idx] = (mg > 0.f) ? mk(X.x * im, X.y * im) : mk(a.unit_default, 0.f);
                 } else {
                     // dL/dc = Re(G conj P) with G = (2/N) rfft(.)  [adjoint of irfft on interior bins]
                     const bool pre = pre_ok && r < 5;
@@ -257,9 +273,9 @@ __global__ __launch_bounds__(kThreads) void analysis_kernel(AnalysisArgs a) {
                         else { mo = a.mom[idx]; ve = a.vel[idx]; p = a.coef[idx]; blo = a.lo[idx]; bhi = a.hi[idx]; }
                         mo = mo + a.hyp.x * (g - mo);                    // exp_avg.lerp_(grad, 1-beta1)
                         ve = ve * a.hyp.y + (a.hyp.z * g) * g;          // mul_(beta2).addcmul_(g, g, 1-beta2)
-                        float den = sqrtf(ve / sc.z) + a.hyp.w;
-                        p = p + (sc.x * g) / den;
-                        p = p + (sc.y * mo) / den;
+                        const float rden = fast_rcp(fast_sqrt(ve * inv_bc2) + a.hyp.w);   // 1 / (sqrt(v / bias_corr2) + eps)
+                        p = p + (sc.x * g) * rden;
+                        p = p + (sc.y * mo) * rden;
                         p = fminf(fmaxf(p, blo), bhi);
                         a.mom[idx] = mo; a.vel[idx] = ve; a.coef[idx] = p;
                         if (improved) a.best[idx] = p;
@@ -439,7 +455,7 @@ __global__ __launch_bounds__(kThreads) void synth_kernel(SynthArgs a) {
             const int j = j0 + tid + kThreads * it;
             if (j < j1) {
                 const int p = kHalf + j;
-                float v = ola[p - pbase] / (small_t ? ola_envelope_loop(a.plan.window2, p, T) : envv[it]);
+                float v = ola[p - pbase] * fast_rcp(small_t ? ola_envelope_loop(a.plan.window2, p, T) : envv[it]);
                 if (add) v += addv[it];
                 out[j] = v;
                 best = umax64(best, pack_max(fabsf(v), (unsigned)j));
@@ -455,6 +471,7 @@ __global__ __launch_bounds__(kThreads) void synth_kernel(SynthArgs a) {
         // adjoint of reflect padding: fold the two 512-sample pads back, then the partial
         // dot product with the normalised forward signal for the normaliser's backward
         const float* y = a.yraw + sig_offset(a.frame_off, b);
+        const float inv_m = 1.0f / cn.m, inv_m2 = 1.0f / cn.m2;
         double acc = 0.0;
         float yv[NOUT];
 #pragma unroll
@@ -470,7 +487,7 @@ __global__ __launch_bounds__(kThreads) void synth_kernel(SynthArgs a) {
                 if (j >= 1 && j <= kHalf) g += ola[kHalf - j - pbase];
                 if (j >= Ny - kHalf - 1 && j <= Ny - 2) g += ola[2 * Ny + kHalf - 2 - j - pbase];
                 out[j] = g;
-                float y2 = (yv[it] / cn.m) / cn.m2;
+                float y2 = (yv[it] * inv_m) * inv_m2;
                 acc += (double)g * (double)y2;
             }
         }

@@ -195,10 +195,32 @@ def test_detector_forward_and_detect(rt, plan, det, O):
         np.testing.assert_allclose(v, e["raw_unmarked"], atol=5e-5)
 
 
-@pytest.mark.parametrize("lengths,seeds", [([16000], [1]), ([48000, 16000, 23456], [0, 1, 2])])
+def _min_kink_distance(emb, mag0, phase):
+    """Smallest |u| over all LeakyReLU arguments of the detector for this clip (oracle forward).  The loss is not
+    differentiable where u = 0: when some |u| is within f32 rounding of 0 its sign -- and with it a finite part of
+    the (sub)gradient around that frame -- is decided by rounding, in the reference as much as here."""
+    det = emb.det
+    with torch.no_grad():
+        mag2, _ = emb.recompute_magnitude(mag0, phase)
+        mag2 = mag2.clone()
+        mag2[:, emb.nonband] = 0.0
+        x = det.instance_norm(torch.matmul(det.mel, mag2))
+        x = (x - x.mean(dim=(1, 2), keepdim=True)) / (x.std(dim=(1, 2), keepdim=True) + 1e-8)
+        x = torch.nn.functional.avg_pool1d(x, 2, 2)
+        dist = float("inf")
+        for w, b in zip(det.ws, det.bs):
+            u = det.instance_norm(torch.matmul(w, x) + b[:, None])
+            dist = min(dist, float(u.abs().min()))
+            x = torch.nn.functional.leaky_relu(u, 0.2)
+    return dist
+
+
+@pytest.mark.parametrize("lengths,seeds", [([16000], [1]), ([48000, 16000, 23456], [0, 1, 2]), ([30000, 48000], [8, 9])])
 def test_first_iteration_gradient(rt, plan, det, O, lengths, seeds):
     """dL/dcoef of the first loop body vs torch autograd on the oracle (and the reference's
-    own gradient for the golden seeds)."""
+    own gradient for the golden seeds): 5e-5 relative L2 (measured ~2e-6) unless a LeakyReLU argument of the
+    clip sits within 2e-6 of its kink, where the two sub-gradients differ by a finite amount (seed 0: channel 127 of
+    block 0 at pooled frame 10 has |u| = 2e-7) -- then 2e-2."""
     pairs = [make_clip(s, n) for s, n in zip(seeds, lengths)]
     cl = [p[0] for p in pairs]
     wm = np.stack([O.bits_to_bipolar(p[1]) for p in pairs]).astype(np.float32)
@@ -219,16 +241,19 @@ def test_first_iteration_gradient(rt, plan, det, O, lengths, seeds):
         l.sum().backward()
         ref = c0.grad[0]                                                    # [225, T]
         mine = g[batch.frame_offsets[i]: batch.frame_offsets[i + 1], :225].T
-        assert abs(loss[i] - float(l)) < 2e-5, (loss[i], float(l))
+        assert abs(loss[i] - float(l.detach())) < 2e-5, (loss[i], float(l.detach()))
         np.testing.assert_allclose(pred[i], p[0].detach().numpy(), atol=5e-5)
         rel = (mine - ref).norm().item() / ref.norm().item()
-        assert rel < 2e-3, rel
+        kink = _min_kink_distance(emb, mag0, phase)
+        print(f"clip {i}: relative L2 error {rel:.2e}, nearest LeakyReLU kink {kink:.1e}")
+        assert rel < (5e-5 if kink > 2e-6 else 2e-2), (rel, kink)
     if seeds[0] == 1 and lengths[0] == 16000:
         e = np.load(os.path.join(GOLDEN, "embed_1s.npz"))
         mine = g[: batch.frames[0], :225].T.numpy()
         ref = e["iter1_grad_sample"]
         rel = np.linalg.norm(mine - ref) / np.linalg.norm(ref)
-        assert rel < 3e-3, rel
+        print("relative L2 distance to the reference's own first gradient:", rel)
+        assert rel < 1e-4, rel
         assert abs(loss[0] - float(e["iter1_loss"])) < 2e-5
 
 
