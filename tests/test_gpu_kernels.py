@@ -348,3 +348,35 @@ def test_first_iteration_x3_vs_f32_pipe(rt, plan, det, O):
     rel = ((g4 - g0).norm() / g0.norm()).item()
     print("relative L2 difference of the gradients, bf16x3 vs f32 MFMA:", rel)
     assert rel < 2e-5, rel
+
+
+@pytest.mark.parametrize("n", [16000, 48000, 33000])
+def test_fused_readout_vs_three_kernel_path(rt, plan, det, O, n):
+    """Uniform batches run the last conv block, BRH, loss, their backward and the last data gradient in
+    readout_x3_kernel (fed by split-K partials from the previous block's epilogue); aware_tune(2, 0) selects the
+    split-K GEMM + tail kernel + data-gradient GEMM that ragged batches use.  Same loss, prediction, gradient,
+    best-loss bookkeeping and step counter from both."""
+    B = 5
+    pairs = [make_clip(60 + i, n) for i in range(B)]
+    wm = np.stack([O.bits_to_bipolar(p[1]) for p in pairs]).astype(np.float32)
+    batch = rt.Batch([n] * B)
+    res = []
+    try:
+        for fused in (1, 0):
+            rt.tune(2, fused)
+            sess = rt.EmbedSession(plan, det, batch, use_graph=False)
+            sess.begin(batch.pack([p[0] for p in pairs]), torch.from_numpy(wm).cuda())
+            g = sess.gradient().cpu().double()
+            l0, p0 = sess.loss.cpu().numpy().copy(), sess.pred.cpu().numpy().copy()
+            sess.iterate(3)
+            torch.cuda.synchronize()
+            res.append((g, l0, p0, sess.loss.cpu().numpy().copy(), sess.best_loss.cpu().numpy().copy(), int(sess.step.cpu()[0])))
+    finally:
+        rt.tune(2, 1)
+    (g1, l1, p1, l1b, b1, s1), (g0, l0, p0, l0b, b0, s0) = res
+    assert np.max(np.abs(l1 - l0)) < 2e-6 and np.max(np.abs(p1 - p0)) < 2e-6
+    rel = ((g1 - g0).norm() / g0.norm()).item()
+    print("relative L2 difference of the gradients, fused vs three-kernel read-out:", rel)
+    assert rel < 2e-5, rel
+    assert s1 == s0 == 3
+    assert np.max(np.abs(l1b - l0b)) < 1e-4 and np.max(np.abs(b1 - b0)) < 1e-4
