@@ -171,11 +171,12 @@ def test_shard_by_cost_balances_and_is_deterministic():
 
 
 def test_product_code_never_imports_the_oracle():
-    """oracle/ is test infrastructure: nothing under aware_amd/ (nor bench.py outside its
+    """oracle/ is test infrastructure: nothing under aware_amd/, aware/ or tools/ (nor bench.py outside its
     cpu_baseline leg) may import it."""
     import ast
     bad = []
-    for dirpath, _, files in os.walk(os.path.join(ROOT, "aware_amd")):
+    walk = [t for d in ("aware_amd", "aware", "tools") for t in os.walk(os.path.join(ROOT, d))]
+    for dirpath, _, files in walk:
         for f in files:
             if not f.endswith(".py"):
                 continue
