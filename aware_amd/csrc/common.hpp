@@ -11,7 +11,10 @@ namespace aware {
 // every frame row 1 KiB-aligned and makes the row the K dimension of the mel GEMM.
 constexpr int kFS = 256;
 constexpr int kFramesPerWG = 16;     // frames transformed by one 256-thread workgroup
-constexpr int kSynthBlocks = 13;     // hop blocks of output per synthesis workgroup (16 - 3 halo)
+constexpr int kSynthBlocks = 16;     // hop blocks of output per synthesis workgroup (needs up to 19 frames: 3 halo)
+constexpr int kSynthRounds = 5;      // ... transformed in 5 rounds of 4 waves; 187 blocks of a 3 s clip = 12 workgroups,
+                                     // 768 for 64 clips = exactly the 3 resident per CU (13 blocks gave 960: a 25 % tail wave)
+constexpr int kSynthChunk = (kSynthBlocks + 6) * kHop;   // overlap-add buffer: 256*(19 - 1) + 1024 samples
 constexpr int kChunk = (kFramesPerWG + 3) * kHop;   // 4864 floats of LDS signal / OLA buffer
 constexpr int kThreads = 256;
 

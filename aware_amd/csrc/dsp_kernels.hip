@@ -312,7 +312,7 @@ struct SynthArgs {
 // INP: 0 = full one-sided spectrum, 1 = band inside bins 1..256 (prefetched), 2 = any band
 template <int MODE, int INP>
 __global__ __launch_bounds__(kThreads) void synth_kernel(SynthArgs a) {
-    __shared__ float ola[kChunk];
+    __shared__ float ola[kSynthChunk];
     __shared__ cf scratch[4][kFftScratch];
     __shared__ unsigned long long red[4];
     __shared__ double dred[4];
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(kThreads) void synth_kernel(SynthArgs a) {
         if (blockIdx.x == 0) tlo = 0;
         if ((int)blockIdx.x == nseg - 1) thi = T - 1;
     }
-    const int nfr = thi - tlo + 1;              // <= 16 by construction
+    const int nfr = thi - tlo + 1;              // <= kSynthBlocks + 3 = 19 by construction
     const int pbase = kHop * tlo;               // padded position of ola[0]
 
     ClipNorm cn;
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(kThreads) void synth_kernel(SynthArgs a) {
     __shared__ cf tw1s[512];
     __shared__ cf tw2s[64];
     fft_fill_tables(tid, kThreads, a.plan.tw512, tw1s, tw2s);
-    for (int i = tid; i < kChunk; i += kThreads) ola[i] = 0.f;
+    for (int i = tid; i < kSynthChunk; i += kThreads) ola[i] = 0.f;
     __syncthreads();
 
     cf* s = scratch[wave];
@@ -354,8 +354,8 @@ __global__ __launch_bounds__(kThreads) void synth_kernel(SynthArgs a) {
     const float2* win2p = reinterpret_cast<const float2*>(a.plan.window);   // 4 KB, L1-resident
     const int band_lo = a.plan.band_lo, nband = a.plan.nband;
 
-    // 4 rounds; in round r wave w owns frame r + 4w: concurrently processed frames are
-    // 4 hops = 1024 samples apart, so the overlap-add needs no atomics and its
+    // kSynthRounds rounds; in round r wave w owns frame r + kSynthRounds*w: concurrently processed frames are
+    // at least 4 hops = 1024 samples apart, so the overlap-add needs no atomics and its
     // summation order is fixed.
     // Band inputs of one frame.  When the band lies inside bins 1..256 (the model card: 32..256)
     // register slot r needs exactly one input bin: its own bin k = lane+64r for k <= 256, the
@@ -381,10 +381,10 @@ __global__ __launch_bounds__(kThreads) void synth_kernel(SynthArgs a) {
             inA[r] = (f >= 0 && f < nband) ? am : 0.f;
         }
     };
-    if (compact && 4 * wave < nfr) load_band(4 * wave);
+    if (compact && kSynthRounds * wave < nfr) load_band(kSynthRounds * wave);
 #pragma unroll 1
-    for (int r4 = 0; r4 < 4; ++r4) {
-        const int fi = r4 + 4 * wave;
+    for (int r4 = 0; r4 < kSynthRounds; ++r4) {
+        const int fi = r4 + kSynthRounds * wave;
         if (fi < nfr) {
             const size_t row = (size_t)(f0 + tlo + fi);
             cf v[8];
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(kThreads) void synth_kernel(SynthArgs a) {
                     const cf z = mk(0.f, 0.f);
                     v[r] = irfft_merge_bin(k, (k <= 256) ? x : z, (k >= 256) ? x : z, a.plan.tw1024);
                 }
-                if (r4 < 3 && fi + 1 < nfr) load_band(fi + 1);
+                if (r4 < kSynthRounds - 1 && fi + 1 < nfr) load_band(fi + 1);
             } else {
                 const float* A = a.amp + row * kFS;
                 const cf* P = a.ph + row * kFS;
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(kThreads) void synth_kernel(SynthArgs a) {
     const int Ny = kHop * nblk;
     float* out = a.out + sig_offset(a.frame_off, b);
     const int j0 = kHop * jb0, j1 = kHop * jb1;
-    constexpr int NOUT = kSynthBlocks;              // (j1 - j0) / 256 <= 13 passes; loads batched ahead of their use
+    constexpr int NOUT = kSynthBlocks;              // (j1 - j0) / 256 <= 16 passes; loads batched ahead of their use
     const bool small_t = T < 4;
     if (MODE == SY_FWD) {
         const float* add = a.add ? a.add + sig_offset(a.frame_off, b) : nullptr;
