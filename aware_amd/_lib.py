@@ -87,6 +87,7 @@ SIGNATURES = {
     "aware_upfirdn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp]),
     "aware_iir": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "aware_segment_cut": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "aware_phase_vocoder": (_i, [_vp, _vp, _vp, _vp, _i, C.c_double, _vp]),
     "aware_snr": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "aware_gaussian_noise": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _f, _vp, _vp]),
     "aware_spectral_quantize": (_i, [_vp, _i, _f, _f, _vp]),

@@ -238,6 +238,44 @@ class MP3Surrogate(Attack):
         return rt.Ragged(y, batch.out_lengths)
 
 
+@register
+class TimeStretch(Attack):
+    """EXTENSION in place of scripts/attacks.py:208-228 (pyrubberband -> rubberband binary, absent): phase-vocoder
+    time-scale modification on the STFT kernels.  rate > 1: faster / shorter, rate < 1: slower / longer.  Specified by
+    oracle/aware_oracle.py::time_stretch_attack -- parity with rubberband unpinned.  Output length 256*(ceil(T/rate)-1)."""
+
+    def __init__(self, rate=1.0):
+        self.rate = float(rate)
+        self.name = f"ts_{rate}"
+
+    def apply_batch(self, x, sr):
+        from .utils.audio import default_plan
+        return rt.time_stretch(default_plan(), x, self.rate)
+
+
+@register
+class PitchShift(Attack):
+    """EXTENSION in place of scripts/attacks.py:231-252: pitch shift by `cents`/100 semitones (the reference's own
+    unit conversion, :249) = phase-vocoder stretch by 2^(semitones/12) followed by polyphase resampling back to the
+    original duration.  Specified by oracle/aware_oracle.py::pitch_shift_attack -- parity with rubberband unpinned."""
+
+    def __init__(self, cents=5):
+        self.cents = cents
+        self.name = f"ps_{cents}"
+
+    def ratio(self):
+        from fractions import Fraction
+        factor = 2.0 ** ((self.cents / 100.0) / 12.0)
+        fr = Fraction(1.0 / factor).limit_denominator(512)          # resampling ratio up/down ~ 1/factor
+        return factor, fr.numerator, fr.denominator
+
+    def apply_batch(self, x, sr):
+        from .utils.audio import default_plan
+        factor, up, down = self.ratio()
+        y = rt.time_stretch(default_plan(), x, 1.0 / factor)
+        return y if up == down else resample_poly_batch(y, up, down)
+
+
 def reference_attack_list():
     """The subset of the harness's 22-entry list (scripts/test.py:15-18) that runs here."""
     return [PCMBitDepthConversion(8), PCMBitDepthConversion(12), PCMBitDepthConversion(16), PCMBitDepthConversion(24),

@@ -370,4 +370,46 @@ void launch_snr(const float* a, const int* a_off, const float* b, const int* b_o
     hipLaunchKernelGGL(snr_kernel, dim3(B), dim3(256), 0, st, a, a_off, b, b_off, len, out);
 }
 
+
+// ---------------------------------------------------------------------------------
+// Phase vocoder (time-scale modification at a fixed hop): resamples a one-sided STFT in time by `rate`
+// (frame t of the output sits at input position t*rate: magnitudes interpolated linearly, phases advanced by the
+// measured per-bin phase increment wrapped to (-pi, pi]) -- the textbook algorithm, as in librosa.phase_vocoder.
+// The reference's TimeStretch / PitchShift shell out to the rubberband binary (scripts/attacks.py:208-252, absent
+// here): this is a stand-in specified by oracle/aware_oracle.py::phase_vocoder, parity with rubberband unpinned.
+// One thread per (clip, bin): the phase accumulation is a sequential scan over time; f64 arithmetic.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void phase_vocoder_kernel(const cf* __restrict__ in, const int* __restrict__ fin,
+                                                            cf* __restrict__ out, const int* __restrict__ fout, double rate) {
+    const int c = blockIdx.y, k = blockIdx.x * 64 + threadIdx.x;
+    if (k > 512) return;
+    const int f0 = fin[c], T = fin[c + 1] - f0, g0 = fout[c], To = fout[c + 1] - g0;
+    const double TWO_PI = 6.283185307179586476925286766559;
+    const double adv = TWO_PI * (double)kHop * (double)k / (double)kNfft;       // expected phase advance per hop
+    const cf* D = in + (size_t)f0 * 520 + k;
+    cf* O = out + (size_t)g0 * 520 + k;
+    cf d0 = D[0];
+    double acc = atan2((double)d0.y, (double)d0.x);
+    for (int t = 0; t < To; ++t) {
+        const double step = (double)t * rate;
+        const int i = (int)floor(step);
+        const double alpha = step - (double)i;
+        cf c0 = mk(0.f, 0.f), c1 = mk(0.f, 0.f);
+        if (i < T) c0 = D[(size_t)i * 520];
+        if (i + 1 < T) c1 = D[(size_t)(i + 1) * 520];
+        const double m0 = sqrt((double)c0.x * c0.x + (double)c0.y * c0.y), m1 = sqrt((double)c1.x * c1.x + (double)c1.y * c1.y);
+        const double mag = (1.0 - alpha) * m0 + alpha * m1;
+        O[(size_t)t * 520] = mk((float)(mag * cos(acc)), (float)(mag * sin(acc)));
+        double dp = atan2((double)c1.y, (double)c1.x) - atan2((double)c0.y, (double)c0.x) - adv;
+        dp -= TWO_PI * rint(dp / TWO_PI);                                       // wrap to [-pi, pi]
+        acc += adv + dp;
+    }
+    if (k < 8) {                                       // keep the 7 pad columns of the 520-wide rows finite
+        for (int t = 0; t < To; ++t) out[(size_t)(g0 + t) * 520 + 513 + (k < 7 ? k : 6)] = mk(0.f, 0.f);
+    }
+}
+void launch_phase_vocoder(const void* in, const int* fin, void* out, const int* fout, double rate, int B, hipStream_t st) {
+    hipLaunchKernelGGL(phase_vocoder_kernel, dim3(9, B), dim3(64), 0, st, (const cf*)in, fin, (cf*)out, fout, rate);
+}
+
 }  // namespace aware

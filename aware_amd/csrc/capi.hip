@@ -1009,6 +1009,14 @@ extern "C" int aware_snr(const float* output, const int* out_offsets, const floa
     return AWARE_OK;
 }
 
+extern "C" int aware_phase_vocoder(const void* spec_in, const int* frame_off_in, void* spec_out, const int* frame_off_out,
+                                   int B, double rate, void* stream) {
+    if (!spec_in || !frame_off_in || !spec_out || !frame_off_out || B < 1 || !(rate > 0.0)) return AWARE_E_BADARG;
+    launch_phase_vocoder(spec_in, frame_off_in, spec_out, frame_off_out, rate, B, (hipStream_t)stream);
+    LAUNCHCHK();
+    return AWARE_OK;
+}
+
 extern "C" int aware_spectral_quantize(void* spec, int n_frames, float step_db, float floor_db, void* stream) {
     if (!spec || n_frames < 1 || !(step_db > 0.f)) return AWARE_E_BADARG;
     launch_spectral_quantize(spec, n_frames, step_db, floor_db, (hipStream_t)stream);

@@ -421,6 +421,32 @@ def gaussian_noise(x: Ragged, snr_db: float, seeds: Sequence[int]) -> Ragged:
     return out
 
 
+def phase_vocoder_frames(frames: Sequence[int], rate: float):
+    """Frames per clip after a phase vocoder at `rate`: len(np.arange(0, T, rate))."""
+    return [int(len(np.arange(0, int(t), float(rate)))) for t in frames]
+
+
+def time_stretch(plan: "Plan", x: Ragged, rate: float) -> Ragged:
+    """STFT -> phase vocoder -> iSTFT of every clip (EXTENSION, see aware_phase_vocoder).  Output length
+    256*(ceil(T/rate) - 1) samples per clip."""
+    lib = load_library()
+    dev = x.data.device
+    bin_ = Batch(x.lengths)
+    spec = stft(plan, bin_, x.data if x.data.dtype == torch.float32 else x.data.float(), normalize=False)
+    to = phase_vocoder_frames(bin_.frames, rate)
+    if min(to) < 3:
+        raise ValueError("time_stretch: a clip would shrink below 3 frames")
+    bout = Batch([256 * (t - 1) + 1 for t in to])                    # a batch whose clips have exactly `to` frames
+    assert bout.frames == to
+    fin = torch.tensor(bin_.frame_offsets, dtype=torch.int32, device=dev)
+    fout = torch.tensor(bout.frame_offsets, dtype=torch.int32, device=dev)
+    out_spec = torch.empty((bout.total_frames, FULL_STRIDE), dtype=torch.complex64, device=dev)
+    check(lib.aware_phase_vocoder(_ptr(spec), _ptr(fin), _ptr(out_spec), _ptr(fout), x.B, float(rate), _stream()),
+          "aware_phase_vocoder")
+    y = istft(plan, bout, out_spec, normalize=False)
+    return Ragged(y, bout.out_lengths)
+
+
 def snr_db(output: Ragged, target: Ragged) -> torch.Tensor:
     """Per-clip SNR in dB of `output` against `target` over the common length (metrics/audio.py:68-89);
     device float64 tensor [B]."""

@@ -191,6 +191,14 @@ int aware_gaussian_noise(const float* in, float* out, const int* off, const int*
  * Used as  aware_stft -> aware_spectral_quantize -> aware_istft. */
 int aware_spectral_quantize(void* spec, int n_frames, float step_db, float floor_db, void* stream);
 
+/* EXTENSION (stand-in for the reference's rubberband-based TimeStretch / PitchShift, scripts/attacks.py:208-252; the
+ * binary is absent, parity with it unpinned): phase vocoder on one-sided spectra [frames][AWARE_FULL_STRIDE] complex64.
+ * Output frame t of clip c sits at input position t*rate: linear magnitude interpolation, phase accumulated from the
+ * wrapped per-bin phase increments (f64).  frame_off_* are device arrays of B+1 frame offsets; the caller sizes
+ * the output as ceil(T_c / rate) frames per clip.  Used as aware_stft -> aware_phase_vocoder -> aware_istft. */
+int aware_phase_vocoder(const void* spec_in, const int* frame_off_in, void* spec_out, const int* frame_off_out, int B,
+                        double rate, void* stream);
+
 /* ---- quality metric ----------------------------------------------------------------------------------
  * SNR.__call__ (src/AWARE/metrics/audio.py:68-89) per clip: 10 log10(mean(output^2) / mean((output - target)^2))
  * over lengths[c] samples (the caller passes the common length, :82-84), +inf when the clips are identical;

@@ -692,3 +692,45 @@ def mp3_surrogate_attack(audio, n_levels_db=1.5, floor_db=-60.0):
     mq = fmax * torch.pow(10.0, q / 20.0)
     mq = torch.where(db < floor_db, torch.zeros_like(mq), mq)
     return istft(mq * torch.exp(1j * ph)).numpy()
+
+
+def phase_vocoder(D, rate, hop=256, n_fft=1024):
+    """EXTENSION -- textbook phase vocoder (librosa.phase_vocoder's algorithm) on a one-sided STFT
+    D [513, T] complex: output frame t sits at input position t*rate; magnitudes interpolated linearly between
+    the two neighbouring frames (zero frame past the end), phase accumulated from the per-bin phase increment minus
+    the expected advance 2*pi*hop*k/n_fft, wrapped to [-pi, pi] with round-half-even.  float64 arithmetic."""
+    D = np.asarray(D).astype(np.complex128)
+    F, T = D.shape
+    steps = np.arange(0, T, float(rate))
+    adv = 2.0 * np.pi * hop * np.arange(F) / n_fft
+    Dp = np.concatenate([D, np.zeros((F, 2), dtype=D.dtype)], axis=1)
+    out = np.zeros((F, len(steps)), dtype=np.complex128)
+    acc = np.angle(D[:, 0])
+    for t, step in enumerate(steps):
+        i = int(np.floor(step))
+        alpha = step - i
+        c0, c1 = Dp[:, i], Dp[:, i + 1]
+        mag = (1.0 - alpha) * np.abs(c0) + alpha * np.abs(c1)
+        out[:, t] = mag * np.exp(1j * acc)
+        dp = np.angle(c1) - np.angle(c0) - adv
+        dp = dp - 2.0 * np.pi * np.round(dp / (2.0 * np.pi))
+        acc = acc + adv + dp
+    return out.astype(np.complex64)
+
+
+def time_stretch_attack(audio, rate):
+    """EXTENSION in place of scripts/attacks.py:208-228 (rubberband): STFT -> phase_vocoder -> iSTFT."""
+    x = torch.as_tensor(np.asarray(audio, dtype=np.float32))
+    S = stft(x).numpy()
+    return istft(torch.from_numpy(phase_vocoder(S, rate))).numpy()
+
+
+def pitch_shift_attack(audio, cents):
+    """EXTENSION in place of scripts/attacks.py:231-252: stretch by 2^(cents/1200) then polyphase resampling back
+    (ratio from Fraction(1/factor).limit_denominator(512), scipy.signal.resample_poly)."""
+    from fractions import Fraction
+    from scipy.signal import resample_poly as _rp
+    factor = 2.0 ** ((cents / 100.0) / 12.0)
+    fr = Fraction(1.0 / factor).limit_denominator(512)
+    y = time_stretch_attack(audio, 1.0 / factor)
+    return y if fr.numerator == fr.denominator else _rp(y.astype(np.float32), fr.numerator, fr.denominator).astype(np.float32)

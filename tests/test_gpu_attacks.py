@@ -144,3 +144,34 @@ def test_snr_on_gpu(A):
     # and against the host metric class (float32 numpy arithmetic like the reference)
     from aware_amd.metrics import SNR
     assert abs(SNR()(a[0], b[0]) - got[0]) < 1e-3
+
+
+@pytest.mark.parametrize("rate", [0.9, 1.0, 1.1, 1.37])
+def test_time_stretch_extension(A, rate):
+    """Phase-vocoder TimeStretch against its oracle restatement (the reference shells out to rubberband: parity with
+    it unpinned), ragged batch; rate 1.0 must be the STFT/iSTFT identity."""
+    from oracle import aware_oracle as O
+    from aware_amd import runtime as rt
+    clips = [make_clip(70 + i, n)[0] for i, n in enumerate((16000, 24000, 9000))]
+    x = rt.Ragged.from_list(clips)
+    y = A.TimeStretch(rate).apply_batch(x, 16000).to_list()
+    for a, got in zip(clips, y):
+        ref = O.time_stretch_attack(a, rate)
+        assert got.shape == ref.shape, (got.shape, ref.shape)
+        assert np.max(np.abs(got - ref)) < 2e-5 * max(1.0, np.max(np.abs(ref)))
+        T = 1 + len(a) // 256
+        assert len(got) == 256 * (len(np.arange(0, T, rate)) - 1)
+        if rate == 1.0:
+            assert np.max(np.abs(got - a[: len(got)])) < 5e-6
+
+
+def test_pitch_shift_extension(A):
+    from oracle import aware_oracle as O
+    a = make_clip(75, 16000)[0]
+    for cents in (5, 100, -200):
+        got = A.PitchShift(cents).apply(a, 16000)
+        ref = O.pitch_shift_attack(a, cents)
+        assert got.shape == ref.shape
+        assert np.max(np.abs(got - ref)) < 5e-5 * max(1.0, np.max(np.abs(ref)))
+        assert abs(len(got) - len(a)) < 0.02 * len(a) + 1024          # back to (about) the original duration
+    assert A.PitchShift(5).name == "ps_5" and A.TimeStretch(1.1).name == "ts_1.1"

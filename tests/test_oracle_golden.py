@@ -194,3 +194,31 @@ def test_config1_44k():
     assert str(a16.dtype) == str(c["a16_dtype"])
     np.testing.assert_allclose(a16[::16], c["a16_sample"], atol=2e-7)
     np.testing.assert_array_equal(c["det_bits"], bits)
+
+
+def test_phase_vocoder_extension_properties():
+    """The phase-vocoder stand-in for the rubberband attacks has no reference output to pin it (binary absent):
+    check the algorithm's defining properties instead -- rate 1 is the STFT/iSTFT identity, the frame count is
+    len(arange(0, T, rate)), and a stationary sinusoid keeps its frequency under stretching."""
+    rng = np.random.default_rng(3)
+    x = (0.1 * rng.standard_normal(16000)).astype(np.float32)
+    y = O.time_stretch_attack(x, 1.0)
+    assert y.shape == (256 * (16000 // 256),) and np.max(np.abs(y - x[: len(y)])) < 5e-6
+    n = 16000
+    t = np.arange(n) / 16000.0
+    tone = (0.5 * np.sin(2 * np.pi * 1000.0 * t)).astype(np.float32)          # bin 64 exactly
+    for rate in (0.8, 1.25):
+        z = O.time_stretch_attack(tone, rate)
+        T = 1 + n // 256
+        assert len(z) == 256 * (len(np.arange(0, T, rate)) - 1)
+        mid = z[2048:-2048]
+        spec = np.abs(np.fft.rfft(mid * np.hanning(len(mid))))
+        f_peak = np.argmax(spec) * 16000.0 / len(mid)
+        assert abs(f_peak - 1000.0) < 16000.0 / len(mid) + 1e-6
+        # a plain (not phase-locked) vocoder smears a sinusoid over the window's main lobe: the level drops, the tone stays
+        assert 0.25 < np.sqrt(2 * np.mean(mid.astype(np.float64) ** 2)) < 0.55
+    z = O.pitch_shift_attack(tone, 100)                                          # +1 semitone
+    mid = z[2048:-2048]
+    spec = np.abs(np.fft.rfft(mid * np.hanning(len(mid))))
+    f_peak = np.argmax(spec) * 16000.0 / len(mid)
+    assert abs(f_peak - 1000.0 * 2 ** (1 / 12)) < 3.0
