@@ -413,111 +413,6 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_clip_kernel(const float* 
     clip_epilogue<NWM, NWN, EPI>(acc, red1, red2, wm, wn, li, lh, clip, bm, bn, Tp, N, ldc, bias, C, rstd_io, act);
 }
 
-// 16 zero bytes: source of out-of-range chunks for the direct-to-LDS loads
-__device__ float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
-
-// Same GEMM with the operand tiles brought in by direct-to-LDS loads
-// (global_load_lds_dwordx4: no VGPR staging, no ds_write; the load of K tile kt+1 is in
-// flight while tile kt is consumed; one barrier per K tile).  The LDS image of a tile is
-// [rows][32 floats] unpadded, lane-linear as the instruction writes it (wave-uniform base +
-// lane*16 B); bank conflicts of the ds_read_b128 fragment reads are avoided by an XOR swizzle
-// of the 16-byte chunk index with (row>>1)&7, applied to the per-lane SOURCE address when
-// loading and to the read address when consuming.
-template <int NWM, int NWN, int EPI>
-__global__ __launch_bounds__(64 * NWM * NWN) void gemm_clip_glds_kernel(const float* __restrict__ A, int lda,
-                                                                         const float* __restrict__ Bt, int ldb,
-                                                                         const float* __restrict__ bias,
-                                                                         float* __restrict__ C, int ldc, int Tp, int N, int K,
-                                                                         int tiles_n, int ntiles, float* __restrict__ rstd_io,
-                                                                         const float* __restrict__ act) {
-    constexpr int BM = 32 * NWM, BN = 32 * NWN, BK = 32, NW = NWM * NWN;
-    constexpr int TILE = (BM + BN) * BK;                 // floats per buffer
-    __shared__ float smem[2 * TILE + 2 * NWM * BN];     // one LDS object (tiles + epilogue reductions)
-    float (*red1)[BN] = reinterpret_cast<float (*)[BN]>(smem + 2 * TILE);
-    float (*red2)[BN] = reinterpret_cast<float (*)[BN]>(smem + 2 * TILE + NWM * BN);
-
-    int id = blockIdx.x;
-    if ((ntiles & 7) == 0) id = (id & 7) * (ntiles >> 3) + (id >> 3);
-    const int clip = id / tiles_n;
-    const int bm = clip * BM;
-    const int bn = (id % tiles_n) * BN;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / NWN, wn = wave % NWN;
-    const int li = lane & 31, lh = lane >> 5;
-
-    f32x16 acc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-
-    // One load instruction covers 8 tile rows (1 KiB); instruction j of a tile: rows 8j..8j+7.  Each wave
-    // owns instructions j = wave, wave+NW, ...; their per-lane source pointers are computed once (the swizzled
-    // chunk of a lane is fixed), a K tile only adds k0.  Requires K % 32 == 0 (checked by the launcher).
-    constexpr int NJ = ((BM + BN) / 8 + NW - 1) / NW;
-    const int lrow8 = lane >> 3, lslot = lane & 7;
-    const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) float*)smem);
-    const float* srcp[NJ];
-    int kmul[NJ];
-    unsigned dsto[NJ];
-#pragma unroll
-    for (int i = 0; i < NJ; ++i) {
-        const int j = wave + i * NW;
-        const int r = 8 * j + lrow8;                              // row inside [A rows | B rows]
-        const int chunk = lslot ^ ((r >> 1) & 7);                 // logical 16-byte chunk this lane fetches
-        const bool valid = (j < (BM + BN) / 8) && (r < BM || bn + r - BM < N);
-        if (r < BM) srcp[i] = A + (size_t)(bm + r) * lda + 4 * chunk;
-        else srcp[i] = Bt + (size_t)(bn + r - BM) * ldb + 4 * chunk;
-        if (!valid) srcp[i] = g_zero16;
-        kmul[i] = valid ? 1 : 0;
-        dsto[i] = lds_base + (unsigned)(8 * j * BK * sizeof(float));
-    }
-    auto issue = [&](int k0, int buf) {
-#pragma unroll
-        for (int i = 0; i < NJ; ++i) {
-            if (wave + i * NW < (BM + BN) / 8) {
-                const float* src = srcp[i] + k0 * kmul[i];
-                // Inline asm on purpose: hipcc orders every later ds_read behind a pending
-                // __builtin_amdgcn_global_load_lds with s_waitcnt vmcnt(0) (it cannot tell the two LDS
-                // buffers apart), which would serialise the load of tile kt+1 with the MFMAs of tile kt.
-                // The wait this kernel needs is the explicit vmcnt(0) + barrier at the top of the loop.
-                const unsigned dst = dsto[i] + (unsigned)(buf * TILE * sizeof(float));          // wave-uniform
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(dst), "v"(src) : "memory");
-            }
-        }
-    };
-    const int nk = K / BK;
-    issue(0, 0);
-    const int arow = wm * 32 + li, brow = BM + wn * 32 + li;
-    const int asw = (arow >> 1) & 7, bsw = (brow >> 1) & 7;
-    for (int kt = 0; kt < nk; ++kt) {
-        // tile kt has landed for this wave's loads; after the barrier it is visible to all waves and
-        // every wave has finished reading the other buffer (tile kt-1)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const float* t = smem + (kt & 1) * TILE;
-        float4 af[4], bf[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            af[g] = *reinterpret_cast<const float4*>(&t[arow * BK + 4 * ((2 * g + lh) ^ asw)]);
-            bf[g] = *reinterpret_cast<const float4*>(&t[brow * BK + 4 * ((2 * g + lh) ^ bsw)]);
-        }
-        // order: fragment reads, then the next tile's loads, then the MFMAs (the scheduler otherwise sinks
-        // the reads next to their use and exposes the LDS latency once per 4 MFMAs)
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < nk) issue((kt + 1) * BK, (kt + 1) & 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].x, bf[g].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].y, bf[g].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].z, bf[g].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].w, bf[g].w, acc, 0, 0, 0);
-        }
-    }
-    clip_epilogue<NWM, NWN, EPI>(acc, red1, red2, wm, wn, li, lh, clip, bm, bn, Tp, N, ldc, bias, C, rstd_io, act);
-}
-
 template <int NWM, int NWN, int EPI, int BK, int DB>
 static void clip_launch(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc, int B,
                         int Tp, int N, int K, float* rstd_io, const float* act, hipStream_t st) {
@@ -532,8 +427,7 @@ static void clip_launch(const float* A, int lda, const float* Bt, int ldb, const
 
 // rows_per_clip = 32 * nwm (1..4).  epi: 0 plain, 1 forward IN+LeakyReLU, 2 backward of IN+LeakyReLU.
 // cfg: 4 (default) = bf16 matrix-pipe kernel with three-way operand split (gemm_x3.hip) wherever the shape allows,
-// else as 0.  f32-MFMA variants (bit-identical among themselves): 0 = BK 32 / one LDS buffer, 1 = BK 64 / one
-// buffer, 2 = BK 32 / two buffers, 3 = direct-to-LDS loads with two buffers
+// else as 0; 0 = f32-MFMA kernel everywhere (BK 32, one LDS buffer, two-deep register prefetch)
 static int g_clip_cfg = 4;
 void set_gemm_clip_config(int cfg) { g_clip_cfg = cfg; }
 int get_gemm_clip_config() { return g_clip_cfg; }
@@ -547,19 +441,7 @@ void launch_gemm_clip(const float* A, int lda, const float* Bt, int ldb, const f
     if (epi == EPI_FWD) { CLM(EPI_FWD, K_, D_) }      \
     else if (epi == EPI_BWD) { CLM(EPI_BWD, K_, D_) } \
     else { CLM(EPI_PLAIN, K_, D_) }
-    if (g_clip_cfg == 3 && (K % 32) == 0) {
-        const int tn = (N + 127) / 128;
-#define GK(M_, E_) hipLaunchKernelGGL((gemm_clip_glds_kernel<M_, 4, E_>), dim3(tn * B), dim3(256 * M_), 0, st, A, lda, Bt, ldb, \
-                                      bias, C, ldc, Tp, N, K, tn, tn * B, rstd_io, act)
-#define GM(E_) switch (nwm) { case 1: GK(1, E_); break; case 2: GK(2, E_); break; case 3: GK(3, E_); break; default: GK(4, E_); break; }
-        if (epi == EPI_FWD) { GM(EPI_FWD) } else if (epi == EPI_BWD) { GM(EPI_BWD) } else { GM(EPI_PLAIN) }
-#undef GM
-#undef GK
-        return;
-    }
-    if (g_clip_cfg == 1) { CLE(64, 1) }
-    else if (g_clip_cfg == 2) { CLE(32, 2) }
-    else { CLE(32, 1) }
+    CLE(32, 1)
 #undef CLE
 #undef CLM
 #undef CL

@@ -47,11 +47,10 @@ typedef struct aware_embed aware_embed;
 
 int aware_version(void);
 const char* aware_last_hip_error(void);
-/* development knob, not part of the drop-in surface: key 1 = kernel of the clip-aligned conv blocks.
- * 4 [default]: bf16 matrix pipe, operands split exactly into three bf16 terms, six partial products per
- * multiply-add, f32 accumulation (f32-equivalent accuracy; csrc/gemm_x3.hip) for K % 64 == 0, N % 128 == 0,
- * f32 MFMA otherwise.  0..3: f32 MFMA everywhere (0: BK 32 x1, 1: BK 64 x1, 2: BK 32 x2, 3: direct-to-LDS
- * loads x2; identical results among 0..3).
+/* development knobs, not part of the drop-in surface.
+ * key 1 = kernel of the clip-aligned conv blocks.  4 [default]: bf16 matrix pipe, operands split exactly into three
+ * bf16 terms, six partial products per multiply-add, f32 accumulation (f32-equivalent accuracy; csrc/gemm_x3.hip) for
+ * K % 64 == 0, N % 128 == 0, f32 MFMA otherwise.  0: f32 MFMA everywhere (the pipe the bf16 kernel is tested against).
  * key 2 = fused read-out kernel of the embed loop on uniform batches (1 [default] / 0: split-K GEMM + tail kernel +
  * data-gradient GEMM, the path ragged batches always take). */
 int aware_tune(int key, int value);
