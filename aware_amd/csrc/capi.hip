@@ -660,12 +660,16 @@ extern "C" int aware_embed_create(aware_embed** out, const aware_plan* plan, con
     {
         HIPCHK(hipMemsetAsync(e->d1, 0, (size_t)b->NP * det->maxc * sizeof(float), st));
         HIPCHK(hipMemsetAsync(e->mag, 0, nsp * sizeof(float), st));
-        gemm_autotune(e->mag, kFS, det->melT, kFS, e->db.xm, 128, b->NF, 128, kFS, st);
-        gemm_autotune(e->db.xm, 128, det->melB, 128, e->gmag, kFS, b->NF, kFS, 128, st);
+        // only the shapes the f32 kernel will actually serve (the bf16x3 kernel takes M % 32 == 0, N % 128 == 0, K % 64 == 0)
+        auto f32_shape = [&](int M, int N, int K, int lda) {
+            return !(get_gemm_clip_config() == 4 && M % 32 == 0 && gemm_clip_x3_supported(1, N, K, lda));
+        };
+        if (f32_shape(b->NF, 128, kFS, kFS)) gemm_autotune(e->mag, kFS, det->melT, kFS, e->db.xm, 128, b->NF, 128, kFS, st);
+        if (f32_shape(b->NF, kFS, 128, 128)) gemm_autotune(e->db.xm, 128, det->melB, 128, e->gmag, kFS, b->NF, kFS, 128, st);
         for (int l = 0; l < det->n_layers; ++l) {
             const int ci = det->ch[l], co = det->ch[l + 1];
-            gemm_autotune(e->d1, ci, det->w[l], ci, e->d2, co, b->NP, co, ci, st);
-            gemm_autotune(e->d1, co, det->wT[l], co, e->d2, ci, b->NP, ci, co, st);
+            if (f32_shape(b->NP, co, ci, ci)) gemm_autotune(e->d1, ci, det->w[l], ci, e->d2, co, b->NP, co, ci, st);
+            if (f32_shape(b->NP, ci, co, co)) gemm_autotune(e->d1, co, det->wT[l], co, e->d2, ci, b->NP, ci, co, st);
         }
         HIPCHK(hipStreamSynchronize(st));
     }
