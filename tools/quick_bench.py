@@ -26,3 +26,8 @@ sess.iterate(iters)
 torch.cuda.synchronize()
 dt = (time.time() - t0) / iters
 print(f"B={B} graph={graph}: {dt*1e3:.3f} ms/iter -> embed 400 iters = {dt*400:.3f} s -> {B*3/(dt*400):.1f} wf-s/s; loss[0]={float(sess.loss[0]):.4f}")
+if len(sys.argv) > 5:                                   # per-kernel breakdown of three eager loop bodies
+    acc = {}
+    for kind, ms in rt.embed_profile(sess, 3):
+        acc[kind] = acc.get(kind, 0.0) + ms / 3
+    print("  us per iteration by kind:", {k: round(v * 1e3, 1) for k, v in acc.items()})
