@@ -260,6 +260,27 @@ def test_full_size_config1_properties(models):
     assert float(r1.values.abs().min()) > 0.15
 
 
+def test_full_size_config2_properties(models):
+    """BASELINE config 2 at full size (256 x 3 s clips from 44.1 kHz, attack stack resample 16k<->44.1k + low-pass +
+    Gaussian noise 20 dB + PCM 16): the clean read-out of every clip is exact, the attacked read-out stays far from
+    chance, SNR of the watermark is finite and in the range the +-6 dB box allows, and a second run is bit-identical
+    up to the detected bits (the noise attack is keyed per clip, so it repeats too)."""
+    from aware_amd.pipeline import WatermarkPipeline, synthetic_clips
+    from aware_amd.attacks import config3_attack_stack
+    emb, det = models
+    audio, bits = synthetic_clips(256, 3.0, 44100, first_seed=5000)
+    pipe = WatermarkPipeline(emb, det, config3_attack_stack(), 16000, "chain")
+    r1 = pipe.run(audio, bits, input_rate=44100, report_snr=True)
+    assert abs(r1.seconds - 768.0) < 1e-9
+    assert int(r1.clean_bit_errors) == 0
+    assert int(r1.bit_errors) <= 0.05 * bits.numel()
+    snr = r1.snr_db.cpu().numpy()
+    assert snr.shape == (256,) and np.all(np.isfinite(snr)) and np.all(snr > 0.0) and np.all(snr < 40.0)
+    r2 = pipe.run(audio, bits, input_rate=44100)
+    assert torch.equal(r1.watermarked.data, r2.watermarked.data)
+    assert torch.equal(r1.bits, r2.bits)
+
+
 def test_degenerate_inputs_stay_finite(models):
     """Silence and the shortest legal clip go through a few optimiser iterations without NaN/Inf
     (zero variance in every InstanceNorm, zero gradients into NAdam, a single pooled frame)."""
