@@ -392,10 +392,169 @@ __global__ __launch_bounds__(64 * NW) void gemm_clip_x3_kernel(const float* __re
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Small-batch (latency) variant of the conv block: when clips x column slabs cannot fill the chip (fewer than ~256
+// workgroups of the kernel above, e.g. the single clip of the service API), one workgroup takes only 16 columns of
+// one clip and its 8 waves split K (K32 steps wave, wave+8, ...): every wave multiplies all rows of the clip with A
+// split in registers straight from global memory -- no LDS staging, no barrier in the loop -- and the 8 partial
+// tiles meet in LDS.  64 workgroups per clip at N = 1024 instead of 8; same arithmetic, same epilogues.
+// ---------------------------------------------------------------------------------------------------
+template <int RG, int EPI>
+__global__ __launch_bounds__(512) void gemm_clip_x3_small_kernel(const float* __restrict__ A, int lda,
+                                                                  const u32x4* __restrict__ Bpk, const float* __restrict__ bias,
+                                                                  float* __restrict__ C, int ldc, int Tp, int N, int K,
+                                                                  int tiles_n, float* __restrict__ rstd_io,
+                                                                  const float* __restrict__ act) {
+    constexpr int MT = 2 * RG;
+    constexpr int FRAG = 1024;
+    __shared__ __attribute__((aligned(16))) unsigned char part[8 * MT * FRAG];
+    __shared__ float red[2][8][16];
+
+    const int clip = blockIdx.x / tiles_n, nt = blockIdx.x % tiles_n;          // nt: 16-column tile
+    const int bm = clip * 32 * RG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int KS2 = K >> 5;
+    const int nsteps = (KS2 - wave + 7) >> 3;             // K32 steps wave, wave + 8, ...
+
+    f32x4 zp[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) zp[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (nsteps > 0) {
+        const float* abase = A + (size_t)(bm + r16) * lda + 8 * kg;
+        const u32x4* bp = Bpk + (size_t)nt * KS2 * 192 + lane;
+        float4 an[MT][2];
+        u32x4 bb[2][3];
+        auto loadA = [&](int m, int i) {
+            i = i < nsteps ? i : nsteps - 1;
+            const float* p = abase + (size_t)(16 * m) * lda + (wave + 8 * i) * 32;
+            an[m][0] = *reinterpret_cast<const float4*>(p);
+            an[m][1] = *reinterpret_cast<const float4*>(p + 4);
+        };
+        auto loadB = [&](int set, int i) {
+            i = i < nsteps ? i : nsteps - 1;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bb[set][p] = bp[(size_t)(wave + 8 * i) * 192 + p * 64];
+        };
+        auto step = [&](int set, int i) {
+            loadB(set ^ 1, i + 1);
+            const bf16x8 b0 = __builtin_bit_cast(bf16x8, bb[set][0]), b1 = __builtin_bit_cast(bf16x8, bb[set][1]),
+                         b2 = __builtin_bit_cast(bf16x8, bb[set][2]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                uint4 q0, q1, q2;
+                split_pair(an[m][0].x, an[m][0].y, q0.x, q1.x, q2.x);
+                split_pair(an[m][0].z, an[m][0].w, q0.y, q1.y, q2.y);
+                split_pair(an[m][1].x, an[m][1].y, q0.z, q1.z, q2.z);
+                split_pair(an[m][1].z, an[m][1].w, q0.w, q1.w, q2.w);
+                loadA(m, i + 1);                       // the same registers, one whole step ahead of their use
+                const bf16x8 a0 = __builtin_bit_cast(bf16x8, q0), a1 = __builtin_bit_cast(bf16x8, q1),
+                             a2 = __builtin_bit_cast(bf16x8, q2);
+                zp[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b0, zp[m], 0, 0, 0);
+                zp[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, zp[m], 0, 0, 0);
+                zp[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b2, zp[m], 0, 0, 0);
+                zp[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, zp[m], 0, 0, 0);
+                zp[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, zp[m], 0, 0, 0);
+                zp[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, zp[m], 0, 0, 0);
+            }
+        };
+#pragma unroll
+        for (int m = 0; m < MT; ++m) loadA(m, 0);
+        loadB(0, 0);
+        for (int i = 0; i < nsteps; i += 2) {
+            step(0, i);
+            if (i + 1 < nsteps) step(1, i + 1);
+            else { bb[0][0] = bb[1][0]; bb[0][1] = bb[1][1]; bb[0][2] = bb[1][2]; }
+        }
+    }
+    // the 8 partial tiles meet in LDS; wave m (< MT) finishes the 16 rows of row tile m
+#pragma unroll
+    for (int m = 0; m < MT; ++m) *reinterpret_cast<f32x4*>(part + (size_t)(wave * MT + m) * FRAG + lane * 16) = zp[m];
+    __syncthreads();
+    const bool wv = wave < MT;
+    f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (wv) {
+#pragma unroll
+        for (int src = 0; src < 8; ++src) z += *reinterpret_cast<const f32x4*>(part + (size_t)(src * MT + wave) * FRAG + lane * 16);
+    }
+    // column sums over the clip's rows: in-lane -> the wave's four row groups -> across the MT waves (LDS)
+    auto colsum = [&](float x, int stage) {
+        x += __shfl_xor(x, 16);
+        x += __shfl_xor(x, 32);
+        if (kg == 0) red[stage][wave][r16] = x;
+        __syncthreads();
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < MT; ++w) t += red[stage][w][r16];
+        return t;
+    };
+    const int col = nt * 16 + r16;
+    const int row0 = 16 * wave + 4 * kg;
+    const float invT = 1.0f / (float)Tp;
+    if (EPI == X3_PLAIN) {
+        if (!wv) return;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) C[(size_t)(bm + row0 + e) * ldc + col] = row0 + e < Tp ? z[e] + bv : 0.f;
+        return;
+    }
+    if (EPI == X3_FWD) {
+        const float bv = bias ? bias[col] : 0.f;
+        float sacc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { z[e] += bv; if (wv && row0 + e < Tp) sacc += z[e]; }
+        const float mean = colsum(sacc, 0) * invT;
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (wv && row0 + e < Tp) { const float d = z[e] - mean; q += d * d; }
+        const float rs = 1.0f / sqrtf(colsum(q, 1) * invT + 1e-5f);
+        if (!wv) return;
+        if (wave == 0 && kg == 0) rstd_io[(size_t)clip * N + col] = rs;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float u = (z[e] - mean) * rs;
+            C[(size_t)(bm + row0 + e) * ldc + col] = row0 + e < Tp ? (u > 0.f ? u : 0.2f * u) : 0.f;
+        }
+        return;
+    }
+    {   // X3_BWD
+        const float rs = rstd_io[(size_t)clip * N + col];
+        float du[4], uv[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int rr = wv ? row0 + e : 0;                                   // idle waves read a valid row, masked below
+            const float av = act[(size_t)(bm + rr) * ldc + col];
+            const bool valid = wv && row0 + e < Tp;
+            uv[e] = valid ? (av > 0.f ? av : av * 5.0f) : 0.f;
+            du[e] = valid ? z[e] * (av > 0.f ? 1.f : 0.2f) : 0.f;
+            s1 += du[e]; s2 += du[e] * uv[e];
+        }
+        const float m1 = colsum(s1, 0) * invT, m2 = colsum(s2, 1) * invT;
+        if (!wv) return;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            C[(size_t)(bm + row0 + e) * ldc + col] = row0 + e < Tp ? rs * (du[e] - m1 - uv[e] * m2) : 0.f;
+    }
+}
+
+// fewer than this many workgroups of the throughput kernel: use the latency variant
+constexpr int kSmallGrid = 128;
+
 void launch_gemm_clip_x3(const float* A, int lda, const void* Bpk, const float* bias, float* C, int ldc, int B, int nwm,
                          int Tp, int N, int K, int epi, float* rstd_io, const float* act, hipStream_t st,
                          const void* lastpk, float* zpart, int CL) {
     const int tn = N / 128;
+    if (tn * B < kSmallGrid && !(epi == X3_FWD && lastpk && zpart) && K % 32 == 0) {
+        const int t16 = N / 16;
+#define SK(M_, E_) hipLaunchKernelGGL((gemm_clip_x3_small_kernel<M_, E_>), dim3(t16 * B), dim3(512), 0, st, A, lda,          \
+                                      (const u32x4*)Bpk, bias, C, ldc, Tp, N, K, t16, rstd_io, act)
+#define SM(E_) switch (nwm) { case 1: SK(1, E_); break; case 2: SK(2, E_); break; case 3: SK(3, E_); break; default: SK(4, E_); break; }
+        if (epi == X3_FWD) { SM(X3_FWD) } else if (epi == X3_BWD) { SM(X3_BWD) } else { SM(X3_PLAIN) }
+#undef SM
+#undef SK
+        return;
+    }
     if (epi == X3_FWD && lastpk && zpart) epi = X3_FWD_LAST;
 #define XK(M_, E_) hipLaunchKernelGGL((gemm_clip_x3_kernel<M_, E_, 8>), dim3(tn * B), dim3(512), 0, st, A, lda,          \
                                       (const u32x4*)Bpk, bias, C, ldc, Tp, N, K, tn, tn * B, rstd_io, act,                \
