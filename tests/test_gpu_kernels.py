@@ -350,7 +350,7 @@ def test_first_iteration_x3_vs_f32_pipe(rt, plan, det, O):
     assert rel < 2e-5, rel
 
 
-@pytest.mark.parametrize("n", [16000, 48000, 33000])
+@pytest.mark.parametrize("n", [16000, 48000, 33000, 64000])
 def test_fused_readout_vs_three_kernel_path(rt, plan, det, O, n):
     """Uniform batches run the last conv block, BRH, loss, their backward and the last data gradient in
     readout_x3_kernel (fed by split-K partials from the previous block's epilogue); aware_tune(2, 0) selects the
@@ -375,8 +375,14 @@ def test_fused_readout_vs_three_kernel_path(rt, plan, det, O, n):
         rt.tune(2, 1)
     (g1, l1, p1, l1b, b1, s1), (g0, l0, p0, l0b, b0, s0) = res
     assert np.max(np.abs(l1 - l0)) < 2e-6 and np.max(np.abs(p1 - p0)) < 2e-6
-    rel = ((g1 - g0).norm() / g0.norm()).item()
-    print("relative L2 difference of the gradients, fused vs three-kernel read-out:", rel)
-    assert rel < 2e-5, rel
+    emb = O.Embedder()
+    for i, (c, _) in enumerate(pairs):
+        sl = slice(batch.frame_offsets[i], batch.frame_offsets[i + 1])
+        rel = ((g1[sl] - g0[sl]).norm() / g0[sl].norm()).item()
+        mag0, phase = emb.analyse(torch.from_numpy(c)[None])
+        kink = _min_kink_distance(emb, mag0, phase)
+        print(f"clip {i}: fused vs three-kernel read-out, relative L2 difference of the gradients {rel:.2e}, "
+              f"nearest LeakyReLU kink {kink:.1e}")
+        assert rel < (2e-5 if kink > 2e-6 else 2e-2), (rel, kink)       # see test_first_iteration_gradient
     assert s1 == s0 == 3
     assert np.max(np.abs(l1b - l0b)) < 1e-4 and np.max(np.abs(b1 - b0)) < 1e-4
