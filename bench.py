@@ -173,9 +173,10 @@ def main():
             fl = 2.0 * rows * (ch[0] * ch[1] + ch[1] * ch[2] + ch[2] * ch[3]) + 2.0 * rows * (ch[3] * ch[2] + ch[2] * ch[1])
             ms = breakdown["gemm_x3_fwd"][0] + breakdown["gemm_x3_bwd"][0]
             nl = breakdown["gemm_x3_fwd"][1] + breakdown["gemm_x3_bwd"][1]
-            name = "aware::gemm_clip_x3_kernel<3,EPI,8> (forward EPI=1 x2 and EPI=3 x1, backward EPI=2 x2 per iteration)"
-            per_kernel = {"gemm_clip_x3_kernel<3,1|3,8>": round(breakdown["gemm_x3_fwd"][0] * 1e3 / breakdown["gemm_x3_fwd"][1], 2),
-                          "gemm_clip_x3_kernel<3,2,8>": round(breakdown["gemm_x3_bwd"][0] * 1e3 / breakdown["gemm_x3_bwd"][1], 2)}
+            rg = (rows // len(batch.frames) + 31) // 32          # 32-row groups per clip
+            name = f"aware::gemm_clip_x3_kernel<{rg},EPI,8> (forward EPI=1 x2 and EPI=3 x1, backward EPI=2 x2 per iteration)"
+            per_kernel = {f"gemm_clip_x3_kernel<{rg},1|3,8>": round(breakdown["gemm_x3_fwd"][0] * 1e3 / breakdown["gemm_x3_fwd"][1], 2),
+                          f"gemm_clip_x3_kernel<{rg},2,8>": round(breakdown["gemm_x3_bwd"][0] * 1e3 / breakdown["gemm_x3_bwd"][1], 2)}
             peak = MFMA_BF16_PEAK_TF / 6.0
             peak_note = ("f32-equivalent peak of this kernel: dense bf16 MFMA peak (2.5 PFLOP/s) / 6 bf16 partial products per "
                          "f32 multiply-add")
@@ -189,7 +190,8 @@ def main():
                           "gemm_clip_kernel<.,.,2,.,.>": round(breakdown["gemm_clip_bwd"][0] * 1e3 / breakdown["gemm_clip_bwd"][1], 2)}
         else:
             fl, ms, nl = flops_iter, all_ms, all_n
-            name = "aware::gemm_nt_kernel (all detector GEMMs of the iteration)"
+            name = ("aware::gemm_clip_x3_kernel<1,0,8> on 32-row blocks (+ gemm_nt_kernel for shapes it does not serve): "
+                    "all detector GEMMs of the iteration, generic path")
             per_kernel = {"gemm_nt_kernel": round(all_ms * 1e3 / all_n, 2)}
         achieved = fl * n_it / (ms * 1e-3) / 1e12
         dsp_ms = sum(breakdown[k][0] for k in ("synth", "analysis", "synth_adjoint", "analysis_adjoint_nadam"))
