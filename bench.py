@@ -192,7 +192,11 @@ def main():
             fl, ms, nl = flops_iter, all_ms, all_n
             name = ("aware::gemm_clip_x3_kernel<1,0,8> on 32-row blocks (+ gemm_nt_kernel for shapes it does not serve): "
                     "all detector GEMMs of the iteration, generic path")
-            per_kernel = {"gemm_nt_kernel": round(all_ms * 1e3 / all_n, 2)}
+            per_kernel = {"gemm_clip_x3_kernel<1,0,8>|gemm_nt_kernel": round(all_ms * 1e3 / all_n, 2)}
+            if os.environ.get("AWARE_TUNE_CLIP", "4") == "4":
+                peak = MFMA_BF16_PEAK_TF / 6.0
+                peak_note = ("f32-equivalent peak of the bf16x3 kernel: dense bf16 MFMA peak (2.5 PFLOP/s) / 6 bf16 partial "
+                             "products per f32 multiply-add")
         achieved = fl * n_it / (ms * 1e-3) / 1e12
         dsp_ms = sum(breakdown[k][0] for k in ("synth", "analysis", "synth_adjoint", "analysis_adjoint_nadam"))
         dsp_bytes = sum(dsp_bytes_per_clip_iter(t) for t in batch.frames) * n_it
