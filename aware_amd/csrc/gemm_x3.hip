@@ -30,10 +30,6 @@
 #include "kernels.h"
 #include "common.hpp"
 
-#ifndef X3_ABLATE
-#define X3_ABLATE 0
-#endif
-
 namespace aware {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -200,15 +196,11 @@ __global__ __launch_bounds__(64 * NW) void gemm_clip_x3_kernel(const float* __re
 #pragma unroll
         for (int q = 0; q < 4; ++q) {                 // quarter = (K32 step q>>1, row half q&1)
             const int t = q >> 1, hf = q & 1;
-#if !(X3_ABLATE & 1)
             if (hf == 0) loadB((t + 1) & 1, kt * 2 + t + 1);          // B fragments one K32 step ahead
-#endif
-#if !(X3_ABLATE & 2)
             if (q < NCH) {
                 split_store_c(q, nxt);
                 gload_c(q, ktn);
             }
-#endif
             if (q < 3) {
                 read_frags((q + 1) & 1, cur + rb[(q + 1) >> 1] + ((q + 1) & 1) * MH * FRAG);
             } else {
@@ -582,13 +574,6 @@ bool gemm_clip_x3_supported(int nwm, int N, int K, int lda) {
 // one 16-row tile per wave, A split in registers straight from global memory, no LDS), then owns 256 of the
 // Cin columns of the data gradient.  Only workgroup g = 0 of a clip writes pred / loss / best tracking.
 // ---------------------------------------------------------------------------------------------------
-#ifdef RO_STAMP
-__device__ unsigned long long g_ro_stamps[16];
-#define STAMP(i) do { if (blockIdx.x == 17 && threadIdx.x == 0) g_ro_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
-extern "C" int aware_debug_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ro_stamps), sizeof(g_ro_stamps)); }
-#else
-#define STAMP(i)
-#endif
 template <int RG, int NC>
 __global__ __launch_bounds__(512) void readout_x3_kernel(const float* __restrict__ hin, int ci,
                                                           const float* __restrict__ zpart, int nslab, size_t slab_stride,
@@ -634,7 +619,6 @@ __global__ __launch_bounds__(512) void readout_x3_kernel(const float* __restrict
         for (int n = 0; n < NC; ++n)
             if (16 * n + r16 >= C) z[n] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    STAMP(2);
     // column sums over the clip's rows: in-lane -> across the four row groups of the wave -> across waves (LDS)
     auto colsum = [&](const float (&v)[NC], int stage, float (&tot)[NC]) {
 #pragma unroll
@@ -780,7 +764,6 @@ __global__ __launch_bounds__(512) void readout_x3_kernel(const float* __restrict
     }
     __syncthreads();
 
-    STAMP(3);
     // ---- phase 3: dL/dh = dZ_last * W, 32 columns per wave, fused backward of the previous block ----
     f32x4 acc[MT][2];
 #pragma unroll
@@ -809,7 +792,6 @@ __global__ __launch_bounds__(512) void readout_x3_kernel(const float* __restrict
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][pa], b[n][pb], acc[m][n], 0, 0, 0);
         }
     }
-    STAMP(4);
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int col = (ntb + n) * 16 + r16;
@@ -843,7 +825,6 @@ __global__ __launch_bounds__(512) void readout_x3_kernel(const float* __restrict
                 dZ[(size_t)(bm + row) * ci + col] = row < Tp ? rsp * (acc[m][n][e] - m1 - u[m][e] * m2) : 0.f;
             }
     }
-    STAMP(5);
 }
 
 bool readout_x3_supported(int nwm, int ci, int C) { return nwm >= 1 && nwm <= 4 && ci % 256 == 0 && C >= 2 && C <= 48 && C % 2 == 0; }
