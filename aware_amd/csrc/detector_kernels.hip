@@ -1122,8 +1122,132 @@ void launch_tail(const float* zpart, int nsplit, size_t slab, const float* bias,
     else { if (nsplit == 4) TL(4, 80); else TL(1, 80); }
 #undef TL
 }
+// ---------------------------------------------------------------------------------
+// The same mel block for clips of at most 192 frames in ONE launch per direction: one 512-thread workgroup per clip
+// keeps the clip's [T][128] tile in registers (thread = channel c, pooled rows g, g+4, ...: the frame pair
+// (2tp, 2tp+1)), so the statistics need no second pass over memory and no partial buffers.
+// ---------------------------------------------------------------------------------
+constexpr int kMelClipFrames = 192;
+constexpr int kMelClipR = kMelClipFrames / 8;       // frame pairs per thread
+
+// sum over the 4 row groups of a channel (threads c, c+128, c+256, c+384), result for every thread
+__device__ __forceinline__ float mel_chan_sum(float v, float (*red)[128], int c, int g) {
+    __syncthreads();
+    red[g][c] = v;
+    __syncthreads();
+    return (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+// sum over the whole workgroup (8 waves)
+__device__ __forceinline__ float mel_block_sum(float v, float* red8) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red8[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return ((red8[0] + red8[1]) + (red8[2] + red8[3])) + ((red8[4] + red8[5]) + (red8[6] + red8[7]));
+}
+
+__global__ __launch_bounds__(512) void mel_norm_clip_fwd_kernel(const float* __restrict__ xm, const int* __restrict__ frame_off,
+                                                                 const int* __restrict__ pool_off, float* __restrict__ x0,
+                                                                 float* __restrict__ stats, float* __restrict__ gstat) {
+    __shared__ float red[4][128];
+    __shared__ float red8[8];
+    const int b = blockIdx.x;
+    const int f0 = frame_off[b], T = frame_off[b + 1] - f0, Tp = T / 2;
+    const int c = threadIdx.x & 127, g = threadIdx.x >> 7;
+    const float* x = xm + (size_t)f0 * 128 + c;
+    float xa[kMelClipR], xb[kMelClipR];
+#pragma unroll
+    for (int i = 0; i < kMelClipR; ++i) {                   // loads first, from clamped rows; masked below
+        const int t = 2 * (g + 4 * i);
+        xa[i] = x[(size_t)min(t, T - 1) * 128];
+        xb[i] = x[(size_t)min(t + 1, T - 1) * 128];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMelClipR; ++i) {
+        const int t = 2 * (g + 4 * i);
+        if (t < T) s += xa[i];
+        if (t + 1 < T) s += xb[i];
+    }
+    const float mu = mel_chan_sum(s, red, c, g) / (float)T;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMelClipR; ++i) {
+        const int t = 2 * (g + 4 * i);
+        if (t < T) { const float d = xa[i] - mu; q += d * d; }
+        if (t + 1 < T) { const float d = xb[i] - mu; q += d * d; }
+    }
+    const float M2 = mel_chan_sum(q, red, c, g);
+    const float rs = 1.0f / sqrtf(M2 / (float)T + 1e-5f);            // biased var, eps 1e-5 (InstanceNorm1d)
+    const float suu = mel_block_sum(g == 0 ? rs * rs * M2 : 0.f, red8);
+    const float n = (float)T * 128.f;
+    const float gs = sqrtf(suu / (n - 1.f));                          // unbiased std of u (mean 0): GlobalStandardize
+    const float ginv = 1.0f / (gs + 1e-8f);
+    if (g == 0) { float* st = stats + ((size_t)b * 128 + c) * 4; st[0] = mu; st[1] = rs; st[2] = M2; st[3] = 0.f; }
+    if (threadIdx.x == 0) { gstat[b * 4 + 0] = ginv; gstat[b * 4 + 1] = gs; gstat[b * 4 + 2] = n; gstat[b * 4 + 3] = (float)T; }
+    float* o = x0 + (size_t)pool_off[b] * 128 + c;
+    const int Tpad = (Tp + 31) & ~31;
+#pragma unroll
+    for (int i = 0; i < kMelClipR; ++i) {
+        const int tp = g + 4 * i;
+        const float u0 = (xa[i] - mu) * rs, u1 = (xb[i] - mu) * rs;
+        if (tp < Tp) o[(size_t)tp * 128] = 0.5f * (u0 * ginv + u1 * ginv);       // AvgPool1d(2, 2)
+        else if (tp < Tpad) o[(size_t)tp * 128] = 0.f;                            // pad rows stay finite
+    }
+}
+
+__global__ __launch_bounds__(512) void mel_norm_clip_bwd_kernel(const float* __restrict__ dx0, float* __restrict__ xm,
+                                                                 const int* __restrict__ frame_off, const int* __restrict__ pool_off,
+                                                                 const float* __restrict__ stats, const float* __restrict__ gstat) {
+    __shared__ float red[4][128];
+    __shared__ float red8[8];
+    const int b = blockIdx.x;
+    const int f0 = frame_off[b], T = frame_off[b + 1] - f0, Tp = T / 2;
+    const int c = threadIdx.x & 127, g = threadIdx.x >> 7;
+    const float* st = stats + ((size_t)b * 128 + c) * 4;
+    const float mu = st[0], rs = st[1], M2 = st[2];
+    const float ginv = gstat[b * 4 + 0], gs = gstat[b * 4 + 1], n = gstat[b * 4 + 2];
+    float* x = xm + (size_t)f0 * 128 + c;
+    const float* d0 = dx0 + (size_t)pool_off[b] * 128 + c;
+    float xa[kMelClipR], xb[kMelClipR], dd[kMelClipR];
+#pragma unroll
+    for (int i = 0; i < kMelClipR; ++i) {
+        const int tp = g + 4 * i, t = 2 * tp;
+        xa[i] = x[(size_t)min(t, T - 1) * 128];
+        xb[i] = x[(size_t)min(t + 1, T - 1) * 128];
+        dd[i] = d0[(size_t)min(tp, max(Tp - 1, 0)) * 128];
+    }
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMelClipR; ++i) {
+        const bool pair = g + 4 * i < Tp;
+        const float dv = pair ? 0.5f * dd[i] : 0.f;                   // d(avg pool): half the pooled gradient to each frame
+        dd[i] = dv;
+        xa[i] = (xa[i] - mu) * rs;                                    // u
+        xb[i] = (xb[i] - mu) * rs;
+        if (pair) { a1 += 2.f * dv; a2 += dv * xa[i] + dv * xb[i]; }
+    }
+    const float D1 = mel_chan_sum(a1, red, c, g), D2 = mel_chan_sum(a2, red, c, g);
+    const float sa = mel_block_sum(g == 0 ? D1 : 0.f, red8);
+    const float sb = mel_block_sum(g == 0 ? D2 : 0.f, red8);
+    const float mdv = sa / n;
+    const float Q = (gs > 0.f) ? sb * ginv * ginv / ((n - 1.f) * gs) : 0.f;
+    const float m1 = ginv * (D1 / (float)T - mdv);
+    const float m2 = (ginv * D2 - Q * rs * rs * M2) / (float)T;
+#pragma unroll
+    for (int i = 0; i < kMelClipR; ++i) {
+        const int t = 2 * (g + 4 * i);
+        if (t < T) { const float u = xa[i]; x[(size_t)t * 128] = rs * (((dd[i] - mdv) * ginv - u * Q) - m1 - u * m2); }
+        if (t + 1 < T) { const float u = xb[i]; x[(size_t)(t + 1) * 128] = rs * (((dd[i] - mdv) * ginv - u * Q) - m1 - u * m2); }
+    }
+}
+
 void launch_mel_norm_fwd(const float* xm, const int* frame_off, const int* pool_off, float* x0, float* stats,
                          float* gstat, float* part, int pstride, int B, int max_frames, hipStream_t st) {
+    if (max_frames <= kMelClipFrames) {
+        hipLaunchKernelGGL(mel_norm_clip_fwd_kernel, dim3(B), dim3(512), 0, st, xm, frame_off, pool_off, x0, stats, gstat);
+        return;
+    }
     const int nx = (max_frames + kMelChunk - 1) / kMelChunk;
     hipLaunchKernelGGL(mel_partial_stats_kernel, dim3(nx, B), dim3(256), 0, st, xm, frame_off, part, pstride);
     hipLaunchKernelGGL(mel_apply_pool_kernel, dim3(nx, B), dim3(256), 0, st, xm, frame_off, pool_off, part, pstride, x0, stats,
@@ -1131,6 +1255,10 @@ void launch_mel_norm_fwd(const float* xm, const int* frame_off, const int* pool_
 }
 void launch_mel_norm_bwd(const float* dx0, float* xm, const int* frame_off, const int* pool_off, const float* stats,
                          const float* gstat, float* part, int pstride, int B, int max_frames, hipStream_t st) {
+    if (max_frames <= kMelClipFrames) {
+        hipLaunchKernelGGL(mel_norm_clip_bwd_kernel, dim3(B), dim3(512), 0, st, dx0, xm, frame_off, pool_off, stats, gstat);
+        return;
+    }
     const int nx = (max_frames + kMelChunk - 1) / kMelChunk;
     hipLaunchKernelGGL(mel_bwd_partial_kernel, dim3(nx, B), dim3(256), 0, st, dx0, xm, frame_off, pool_off, stats, part, pstride);
     hipLaunchKernelGGL(mel_bwd_apply_kernel, dim3(nx, B), dim3(256), 0, st, dx0, xm, frame_off, pool_off, stats, gstat, part,
