@@ -607,13 +607,26 @@ __global__ __launch_bounds__(512) void readout_x3_kernel(const float* __restrict
     for (int n = 0; n < NC; ++n) z[n] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (wave < MT) {
         const float* zp = zpart + (size_t)(bm + 16 * wave + 4 * kg) * C;
-        for (int sl = 0; sl < nslab; ++sl) {
+        for (int sl0 = 0; sl0 < nslab; sl0 += 4) {                  // four slabs' loads in flight per round
+            float t[4][NC][4];
 #pragma unroll
-            for (int n = 0; n < NC; ++n) {
-                const int c = 16 * n + r16 < C ? 16 * n + r16 : C - 1;       // clamped, not branched: loads stay batched
+            for (int j = 0; j < 4; ++j) {
+                const int sl = sl0 + j < nslab ? sl0 + j : nslab - 1;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) z[n][e] += zp[(size_t)sl * slab_stride + (size_t)e * C + c];
+                for (int n = 0; n < NC; ++n) {
+                    const int c = 16 * n + r16 < C ? 16 * n + r16 : C - 1;   // clamped, not branched: loads stay batched
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[j][n][e] = zp[(size_t)sl * slab_stride + (size_t)e * C + c];
+                }
             }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (sl0 + j < nslab) {
+#pragma unroll
+                    for (int n = 0; n < NC; ++n)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) z[n][e] += t[j][n][e];
+                }
         }
 #pragma unroll
         for (int n = 0; n < NC; ++n)
@@ -738,8 +751,23 @@ __global__ __launch_bounds__(512) void readout_x3_kernel(const float* __restrict
             if (wv && 16 * wave + 4 * kg + e < Tp) { const float du = ga[n] * (z[n][e] > 0.f ? 1.f : 0.2f); s1 += du; s2 += du * z[n][e]; }
         v[n] = s1; v2[n] = s2;
     }
-    colsum(v, 3, tot);
-    colsum(v2, 4, tot2);
+    {   // both sums through one barrier
+#pragma unroll
+        for (int n = 0; n < NC; ++n) {
+            float x = v[n], y = v2[n];
+            x += __shfl_xor(x, 16); x += __shfl_xor(x, 32);
+            y += __shfl_xor(y, 16); y += __shfl_xor(y, 32);
+            if (kg == 0) { red[3][wave][16 * n + r16] = x; red[4][wave][16 * n + r16] = y; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < NC; ++n) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < MT; ++w) { t1 += red[3][w][16 * n + r16]; t2 += red[4][w][16 * n + r16]; }
+            tot[n] = t1; tot2[n] = t2;
+        }
+    }
     if (wv) {
 #pragma unroll
         for (int n = 0; n < NC; ++n) {
@@ -762,21 +790,37 @@ __global__ __launch_bounds__(512) void readout_x3_kernel(const float* __restrict
             }
         }
     }
+    // operands of phase 3 that do not depend on this kernel's own work are requested before the barrier: the weight
+    // fragments and the previous block's activations (read again by the fused backward below)
+    const int ntb = g * 16 + 2 * wave;                  // first 16-column tile of this wave
+    u32x4 bw[KSC][2][3];
+#pragma unroll
+    for (int t = 0; t < KSC; ++t)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bw[t][n][p] = WTpk[(((size_t)(ntb + n) * KSC + t) * 3 + p) * 64 + lane];
+    float hv[2][MT][4];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)     // unconditional (padding rows exist and hold zeros): see gemm_clip_x3_kernel
+                hv[n][m][e] = hin[(size_t)(bm + m * 16 + 4 * kg + e) * ci + (ntb + n) * 16 + r16];
     __syncthreads();
 
     // ---- phase 3: dL/dh = dZ_last * W, 32 columns per wave, fused backward of the previous block ----
     f32x4 acc[MT][2];
 #pragma unroll
     for (int m = 0; m < MT; ++m) { acc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    const int ntb = g * 16 + 2 * wave;                  // first 16-column tile of this wave
 #pragma unroll
     for (int t = 0; t < KSC; ++t) {
         bf16x8 b[2][3], a[MT][3];
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
-                b[n][p] = __builtin_bit_cast(bf16x8, WTpk[(((size_t)(ntb + n) * KSC + t) * 3 + p) * 64 + lane]);
+            for (int p = 0; p < 3; ++p) b[n][p] = __builtin_bit_cast(bf16x8, bw[t][n][p]);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -803,7 +847,7 @@ __global__ __launch_bounds__(512) void readout_x3_kernel(const float* __restrict
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int row = m * 16 + 4 * kg + e;
-                const float av = hin[(size_t)(bm + row) * ci + col];      // unconditional: see gemm_clip_x3_kernel
+                const float av = hv[n][m][e];
                 const bool valid = row < Tp;
                 const float uv = valid ? (av > 0.f ? av : av * 5.0f) : 0.f;                 // invert LeakyReLU(0.2)
                 const float du = valid ? acc[m][n][e] * (av > 0.f ? 1.f : 0.2f) : 0.f;
