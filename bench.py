@@ -236,7 +236,8 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "arithmetic": ("f32 throughout; the detector's conv blocks multiply on the bf16 matrix pipe with every f32 operand split "
                        "exactly into three bf16 terms (six partial products per multiply-add, f32 accumulation): measured error "
-                       "vs fp64 at or below the f32-MFMA chain's (tests/test_gpu_kernels.py::test_gemm_clip_x3)"),
+                       "vs fp64 at or below the f32-MFMA chain's (tests/test_gpu_kernels.py::test_gemm_clip_x3)"
+                       if os.environ.get("AWARE_TUNE_CLIP", "4") == "4" else "f32 throughout (f32-input MFMA)"),
         "config": {"workload": ("config1: %d x %.0f s clips/GPU @44.1 kHz -> 16 kHz, clean embed(400 it)->detect" if not attacks
                                 else "config2: %d x %.0f s clips/GPU @44.1 kHz -> 16 kHz, embed(400 it) -> "
                                      "[resample 16k<->44.1k, lowpass, gaussian 20 dB, pcm16] -> detect") % (per_gpu, args.seconds),
