@@ -386,3 +386,36 @@ def test_fused_readout_vs_three_kernel_path(rt, plan, det, O, n):
         assert rel < (2e-5 if kink > 2e-6 else 2e-2), (rel, kink)       # see test_first_iteration_gradient
     assert s1 == s0 == 3
     assert np.max(np.abs(l1b - l0b)) < 1e-4 and np.max(np.abs(b1 - b0)) < 1e-4
+
+
+def test_fused_path_on_another_detector_geometry(rt, plan, O):
+    """A detector with other layer widths (128 -> 256 -> 512 -> 32, 16 bits): two column slabs in the first block,
+    four split-K slabs and two read-out workgroups per clip, two 16-column tiles in the last block.  The fused
+    bf16x3 path must agree with the f32-MFMA three-kernel path (aware_tune(1, 0) + aware_tune(2, 0))."""
+    g = torch.Generator().manual_seed(11)
+    ch = [128, 256, 512, 32]
+    ws = [((torch.rand(ch[i + 1], ch[i], generator=g) * 2 - 1) * (6.0 / (ch[i] + ch[i + 1])) ** 0.5).numpy() for i in range(3)]
+    bs = [(0.05 * torch.randn(ch[i + 1], generator=g)).numpy() for i in range(3)]
+    det2 = rt.DetectorWeights(plan, O.mel_filter_bank(), ws, bs)
+    B, n = 6, 40000
+    clips = [make_clip(80 + i, n)[0] for i in range(B)]
+    wm = (torch.randint(0, 2, (B, 16), generator=g).float() * 2 - 1)
+    batch = rt.Batch([n] * B)
+    res = []
+    try:
+        for fused in (True, False):
+            rt.tune(1, 4 if fused else 0)
+            rt.tune(2, 1 if fused else 0)
+            sess = rt.EmbedSession(plan, det2, batch, use_graph=False)
+            sess.begin(batch.pack(clips), wm.cuda())
+            grad = sess.gradient().cpu().double()
+            res.append((grad, sess.loss.cpu().numpy().copy(), sess.pred.cpu().numpy().copy()))
+    finally:
+        rt.tune(1, 4)
+        rt.tune(2, 1)
+    (g1, l1, p1), (g0, l0, p0) = res
+    assert p1.shape == (B, 16)
+    assert np.max(np.abs(l1 - l0)) < 5e-6 and np.max(np.abs(p1 - p0)) < 5e-6
+    rel = ((g1 - g0).norm() / g0.norm()).item()
+    print("relative L2 difference of the gradients, fused bf16x3 vs f32 three-kernel path:", rel)
+    assert rel < 1e-3, rel            # loose: a random detector has no guarantee against LeakyReLU kinks
