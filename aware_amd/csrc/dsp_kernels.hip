@@ -381,6 +381,14 @@ __global__ __launch_bounds__(kThreads) void synth_kernel(SynthArgs a) {
             inA[r] = (f >= 0 && f < nband) ? am : 0.f;
         }
     };
+    cf mc[8];                                       // merge constants of this lane's eight bins (compact input only)
+    if (compact) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const cf w = a.plan.tw1024[lane + 64 * r];                  // (cos t, -sin t), t = 2 pi k / 1024
+            mc[r] = (r < 4) ? mk(0.5f * (1.f + w.y), 0.5f * w.x) : mk(0.5f * (1.f - w.y), -0.5f * w.x);
+        }
+    }
     if (compact && kSynthRounds * wave < nfr) load_band(kSynthRounds * wave);
 #pragma unroll 1
     for (int r4 = 0; r4 < kSynthRounds; ++r4) {
@@ -398,12 +406,13 @@ __global__ __launch_bounds__(kThreads) void synth_kernel(SynthArgs a) {
                     v[r] = irfft_merge_bin(k, xk, xp, a.plan.tw1024);
                 }
             } else if (compact) {
+                // irfft merge with one of the two inputs known to be zero (band inside bins 1..256):
+                //   k < 256:  Z[k] = X[k] * (1 + i conj W^k)/2        k >= 256:  Z[k] = conj(X[512-k]) * (1 - i conj W^k)/2
+                // (k = 256 is its own partner and both forms give conj X[256]); the constants sit in registers
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
-                    const int k = lane + 64 * r;
-                    const cf x = mk(inA[r] * inP[r].x, inA[r] * inP[r].y);
-                    const cf z = mk(0.f, 0.f);
-                    v[r] = irfft_merge_bin(k, (k <= 256) ? x : z, (k >= 256) ? x : z, a.plan.tw1024);
+                    const float xr = inA[r] * inP[r].x, xi = (r < 4) ? inA[r] * inP[r].y : -(inA[r] * inP[r].y);
+                    v[r] = mk(xr * mc[r].x - xi * mc[r].y, xr * mc[r].y + xi * mc[r].x);
                 }
                 if (r4 < kSynthRounds - 1 && fi + 1 < nfr) load_band(fi + 1);
             } else {
