@@ -25,25 +25,40 @@ class AwareHipError(RuntimeError):
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP sources for gfx950 into aware_amd/libaware_hip.so (hipcc cross-compiles
-    without a GPU)."""
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in ("common.hpp", "fft512.hpp", "kernels.h")] + [
+    without a GPU).  Each source is compiled to an object under csrc/build/ (only those older than
+    their inputs, in parallel), then linked."""
+    from concurrent.futures import ThreadPoolExecutor
+    hdrs = [os.path.join(CSRC, h) for h in ("common.hpp", "fft512.hpp", "kernels.h")] + [
         os.path.join(_HERE, "..", "include", "aware_hip.h")]
-    if not force and os.path.exists(LIB_PATH):
-        t = os.path.getmtime(LIB_PATH)
-        if all(os.path.getmtime(d) <= t for d in deps):
-            return LIB_PATH
-    cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH] + srcs
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    hdr_t = max(os.path.getmtime(h) for h in hdrs)
+    bdir = os.path.join(CSRC, "build")
+    os.makedirs(bdir, exist_ok=True)
+    flags = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"]
+    jobs, objs = [], []
+    for sname in SOURCES:
+        src = os.path.join(CSRC, sname)
+        obj = os.path.join(bdir, sname.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+            jobs.append(["hipcc"] + flags + ["-c", src, "-o", obj])
+    if not jobs and os.path.exists(LIB_PATH) and all(os.path.getmtime(o) <= os.path.getmtime(LIB_PATH) for o in objs):
+        return LIB_PATH
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=min(5, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs)
     return LIB_PATH
 
 
 class EmbedConfig(C.Structure):
     _fields_ = [("num_iterations", C.c_int), ("tolerance_db", C.c_float), ("loss", C.c_int),
                 ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
-                ("momentum_decay", C.c_float), ("use_graph", C.c_int)]
+                ("momentum_decay", C.c_float), ("use_graph", C.c_int), ("conv_pipe", C.c_int), ("readout", C.c_int)]
 
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
@@ -53,7 +68,6 @@ _pi = C.POINTER(C.c_int)
 SIGNATURES = {
     "aware_version": (_i, []),
     "aware_last_hip_error": (C.c_char_p, []),
-    "aware_tune": (_i, [_i, _i]),
     "aware_plan_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i, _i]),
     "aware_plan_destroy": (None, [_vp]),
     "aware_batch_create": (_i, [C.POINTER(_vp), _i, _pi, _pi]),
@@ -118,10 +132,6 @@ def load_library():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if os.environ.get("AWARE_TUNE_CLIP"):          # development knob, see aware_tune() in the header
-        lib.aware_tune(1, int(os.environ["AWARE_TUNE_CLIP"]))
-    if os.environ.get("AWARE_TUNE_READOUT"):
-        lib.aware_tune(2, int(os.environ["AWARE_TUNE_READOUT"]))
     _lib = lib
     return lib
 

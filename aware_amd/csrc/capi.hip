@@ -89,14 +89,7 @@ struct aware_detector {
     float* bias[8] = {nullptr};
 };
 
-extern "C" int aware_version(void) { return 100; }
-// tuning knob (not part of the drop-in surface): K-tile / buffering of the clip-aligned GEMM
-static int g_fused_readout = 1;
-extern "C" int aware_tune(int key, int value) {
-    if (key == 1) { set_gemm_clip_config(value); return AWARE_OK; }
-    if (key == 2) { g_fused_readout = value != 0; return AWARE_OK; }
-    return AWARE_E_BADARG;
-}
+extern "C" int aware_version(void) { return 200; }
 extern "C" const char* aware_last_hip_error(void) { return g_last_err.c_str(); }
 
 // ---------------------------------------------------------------------------------------------
@@ -423,9 +416,9 @@ extern "C" void aware_detector_destroy(aware_detector* d) {
 
 // Plain GEMM C[M][N] = A[M][K] * Bt^T on the bf16x3 kernel when its packed operand exists and the shape fits
 // (32-row blocks play the role of clips; plain epilogue), else on the f32-MFMA kernel.
-static void gemm_plain(const float* A, int lda, const float* Bt, int ldb, const void* Bpk, const float* bias, float* C,
+static void gemm_plain(int pipe, const float* A, int lda, const float* Bt, int ldb, const void* Bpk, const float* bias, float* C,
                        int ldc, int M, int N, int K, hipStream_t st) {
-    if (get_gemm_clip_config() == 4 && Bpk && M % 32 == 0 && gemm_clip_x3_supported(1, N, K, lda))
+    if (pipe == 0 && Bpk && M % 32 == 0 && gemm_clip_x3_supported(1, N, K, lda))
         launch_gemm_clip_x3(A, lda, Bpk, bias, C, ldc, M / 32, 1, 32, N, K, 0, nullptr, nullptr, st);
     else
         launch_gemm_nt(A, lda, Bt, ldb, bias, C, ldc, M, N, K, st);
@@ -482,8 +475,8 @@ static int clip_tile_groups(const aware_batch* b) {
 
 // forward through the network; mag [NF][256] -> act[last], pred
 static int det_forward(const aware_detector* d, const aware_batch* b, const float* mag, DetBufs& o, hipStream_t st,
-                       bool skip_last = false) {
-    gemm_plain(mag, kFS, d->melT, kFS, d->melTpk, nullptr, o.xm, 128, b->NF, 128, kFS, st);
+                       int pipe = 0, bool skip_last = false) {
+    gemm_plain(pipe, mag, kFS, d->melT, kFS, d->melTpk, nullptr, o.xm, 128, b->NF, 128, kFS, st);
     LAUNCHCHK(); PROF(K_GEMM);
     launch_mel_norm_fwd(o.xm, b->d_frame_off, b->d_pool_off, o.x0, o.mstats, o.gstat, o.mpart, o.mstride, b->B,
                         b->max_frames, st);
@@ -500,7 +493,7 @@ static int det_forward(const aware_detector* d, const aware_batch* b, const floa
             o.tail = 1;
         } else if (nwm && co >= 128) {
             // conv + InstanceNorm + LeakyReLU in one kernel (clip-aligned tiles)
-            if (get_gemm_clip_config() == 4 && d->wpk[l] && gemm_clip_x3_supported(nwm, co, ci, ci)) {
+            if (pipe == 0 && d->wpk[l] && gemm_clip_x3_supported(nwm, co, ci, ci)) {
                 const bool emit = skip_last && l == d->n_layers - 2;   // + split-K partials of the last conv
                 launch_gemm_clip_x3(x, ci, d->wpk[l], d->bias[l], o.act[l], co, b->B, nwm, b->uniform_tp, co, ci, 1, o.rstd[l],
                                     nullptr, st, emit ? d->lastpk : nullptr, emit ? o.zpart : nullptr, d->ch[d->n_layers]);
@@ -511,7 +504,7 @@ static int det_forward(const aware_detector* d, const aware_batch* b, const floa
                 LAUNCHCHK(); PROF(K_GEMM_CLIP_FWD);
             }
         } else {
-            gemm_plain(x, ci, d->w[l], ci, d->wpk[l], d->bias[l], o.act[l], co, b->NP, co, ci, st);
+            gemm_plain(pipe, x, ci, d->w[l], ci, d->wpk[l], d->bias[l], o.act[l], co, b->NP, co, ci, st);
             LAUNCHCHK(); PROF(K_GEMM);
             launch_in_lrelu_fwd(o.act[l], b->d_frame_off, b->d_pool_off, o.rstd[l], co, b->B, b->max_frames / 2, st);
             LAUNCHCHK(); PROF(K_INLRELU);
@@ -594,6 +587,7 @@ struct aware_embed {
     hipGraph_t graph = nullptr, graphN = nullptr;
     hipGraphExec_t gexec = nullptr, gexecN = nullptr;
     hipStream_t cap = nullptr;        // private stream used only to record the graph
+    int steps_done = 0;               // optimiser steps since aware_embed_begin (host mirror of *step)
 };
 
 static size_t embed_bytes(const aware_batch* b, const aware_detector* d, int iters) {
@@ -617,6 +611,7 @@ extern "C" int aware_embed_create(aware_embed** out, const aware_plan* plan, con
                                   size_t workspace_bytes, void* stream) {
     if (!out || !plan || !det || !b || !cfg || !workspace) return AWARE_E_BADARG;
     if (cfg->num_iterations < 1 || cfg->num_iterations > 4096 || cfg->loss < 0 || cfg->loss > 5) return AWARE_E_BADARG;
+    if (cfg->conv_pipe < 0 || cfg->conv_pipe > 1 || cfg->readout < 0 || cfg->readout > 1) return AWARE_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     aware_embed* e = new aware_embed();
     e->plan = plan; e->det = det; e->b = b; e->cfg = *cfg;
@@ -662,7 +657,7 @@ extern "C" int aware_embed_create(aware_embed** out, const aware_plan* plan, con
         HIPCHK(hipMemsetAsync(e->mag, 0, nsp * sizeof(float), st));
         // only the shapes the f32 kernel will actually serve (the bf16x3 kernel takes M % 32 == 0, N % 128 == 0, K % 64 == 0)
         auto f32_shape = [&](int M, int N, int K, int lda) {
-            return !(get_gemm_clip_config() == 4 && M % 32 == 0 && gemm_clip_x3_supported(1, N, K, lda));
+            return !(cfg->conv_pipe == 0 && M % 32 == 0 && gemm_clip_x3_supported(1, N, K, lda));
         };
         if (f32_shape(b->NF, 128, kFS, kFS)) gemm_autotune(e->mag, kFS, det->melT, kFS, e->db.xm, 128, b->NF, 128, kFS, st);
         if (f32_shape(b->NF, kFS, 128, 128)) gemm_autotune(e->db.xm, 128, det->melB, 128, e->gmag, kFS, b->NF, kFS, 128, st);
@@ -734,6 +729,7 @@ extern "C" int aware_embed_begin(aware_embed* e, const float* audio, const float
     HIPCHK(hipMemsetAsync(e->step, 0, 4 * sizeof(int), st));
     // best_loss = +inf (0x7F800000)
     HIPCHK(hipMemsetD32Async((hipDeviceptr_t)e->best_loss, 0x7F800000, b->B, st));
+    e->steps_done = 0;
     return AWARE_OK;
 }
 
@@ -760,31 +756,36 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
     const int nwm = clip_tile_groups(b);
     // one kernel for the last conv block, the BRH head, the loss, their backward and the data gradient of the last
     // conv (uniform batches, bf16x3 configuration); otherwise split-K GEMM + tail kernel + data-gradient GEMM
-    const bool fused_readout = g_fused_readout && get_gemm_clip_config() == 4 && nwm && nl >= 2 && d->lastpk && e->target &&
+    const int pipe = e->cfg.conv_pipe;
+    const bool fused_readout = e->cfg.readout == 0 && pipe == 0 && nwm && nl >= 2 && d->lastpk && e->target &&
                                readout_x3_supported(nwm, d->ch[nl - 1], d->ch[nl]) && d->wpk[nl - 2] &&
                                gemm_clip_x3_supported(nwm, d->ch[nl - 1], d->ch[nl - 2], d->ch[nl - 2]);
-    int rc = det_forward(d, b, e->mag, e->db, st, fused_readout);
+    int rc = det_forward(d, b, e->mag, e->db, st, pipe, fused_readout);
     if (rc) return rc;
     // :109 loss, :120-122 best tracking, gradient seed
     float* dA = e->d1;
     float* dB = e->d2;
     int* step_ptr = do_step ? e->step : nullptr;        // the read-out kernel advances the step counter
+    // aware_embed_gradient (do_step == 0) leaves the best-loss bookkeeping alone: the reference snapshots only
+    // inside the optimiser loop (multibit_embedder.py:120-122)
+    float* best_loss = do_step ? e->best_loss : nullptr;
+    int* improved = do_step ? e->improved : nullptr;
     bool dz_ready = false;      // dA already holds dL/dZ of layer l (fused into the producing kernel)
     int l_top = nl - 1;         // first layer the backward loop below still has to differentiate
     if (fused_readout) {
         launch_readout_x3(e->db.act[nl - 2], d->ch[nl - 1], e->db.zpart, d->ch[nl - 1] / 128, d->bias[nl - 1], d->lastTpk,
-                          e->db.rstd[nl - 2], e->target, e->db.pred, e->loss, e->best_loss, e->improved, step_ptr, dA, b->B,
+                          e->db.rstd[nl - 2], e->target, e->db.pred, e->loss, best_loss, improved, step_ptr, dA, b->B,
                           nwm, b->uniform_tp, d->ch[nl], d->nbits, e->cfg.loss, st);
         dz_ready = true;
         l_top = nl - 2;
     } else if (e->db.tail) {
         launch_tail(e->db.zpart, kTailSplit, (size_t)b->NP * d->ch[nl], d->bias[nl - 1], b->d_frame_off, b->d_pool_off,
-                    e->target, e->db.pred, e->loss, e->best_loss, e->improved, dA, step_ptr, e->cfg.loss, d->nbits, b->B,
+                    e->target, e->db.pred, e->loss, best_loss, improved, dA, step_ptr, e->cfg.loss, d->nbits, b->B,
                     b->max_frames / 2, st);
         dz_ready = true;
     } else {
-        launch_head(e->db.act[nl - 1], b->d_frame_off, b->d_pool_off, e->target, e->db.pred, e->loss, e->best_loss,
-                    e->improved, dA, step_ptr, e->cfg.loss, d->nbits, b->B, st);
+        launch_head(e->db.act[nl - 1], b->d_frame_off, b->d_pool_off, e->target, e->db.pred, e->loss, best_loss,
+                    improved, dA, step_ptr, e->cfg.loss, d->nbits, b->B, st);
     }
     LAUNCHCHK(); PROF(K_HEAD);
     // :111 backward through the detector (data gradients only; weights are frozen :76-77)
@@ -797,7 +798,7 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
         if (nwm && l > 0 && ci >= 128) {
             // data-gradient GEMM whose epilogue is the backward of block l-1's InstanceNorm+LeakyReLU
             dz_ready = true;
-            if (get_gemm_clip_config() == 4 && d->wTpk[l] && gemm_clip_x3_supported(nwm, ci, co, co)) {
+            if (pipe == 0 && d->wTpk[l] && gemm_clip_x3_supported(nwm, ci, co, co)) {
                 launch_gemm_clip_x3(dA, co, d->wTpk[l], nullptr, dB, ci, b->B, nwm, b->uniform_tp, ci, co, 2,
                                     e->db.rstd[l - 1], e->db.act[l - 1], st);
                 LAUNCHCHK(); PROF(K_GEMM_X3_BWD);
@@ -807,7 +808,7 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
                 LAUNCHCHK(); PROF(K_GEMM_CLIP_BWD);
             }
         } else {
-            gemm_plain(dA, co, d->wT[l], co, d->wTpk[l], nullptr, dB, ci, b->NP, ci, co, st);
+            gemm_plain(pipe, dA, co, d->wT[l], co, d->wTpk[l], nullptr, dB, ci, b->NP, ci, co, st);
             dz_ready = false;
             LAUNCHCHK(); PROF(K_GEMM);
         }
@@ -816,7 +817,7 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
     launch_mel_norm_bwd(dA, e->db.xm, b->d_frame_off, b->d_pool_off, e->db.mstats, e->db.gstat, e->db.mpart,
                         e->db.mstride, b->B, b->max_frames, st);
     LAUNCHCHK(); PROF(K_MELNORM);
-    gemm_plain(e->db.xm, 128, d->melB, 128, d->melBpk, nullptr, e->gmag, kFS, b->NF, kFS, 128, st);
+    gemm_plain(pipe, e->db.xm, 128, d->melB, 128, d->melBpk, nullptr, e->gmag, kFS, b->NF, kFS, 128, st);
     LAUNCHCHK(); PROF(K_GEMM);
     // backward through |.|, STFT, reflect padding
     SynthLaunch SA;
@@ -832,7 +833,8 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
     LA.pmax = e->pmaxY; LA.pcount = b->d_pc_syn; LA.pstride = b->pstride;
     LA.adjoint = 1; LA.yraw = e->yraw; LA.pdot = e->pdot; LA.phasor = e->P;
     LA.coef = e->coef; LA.mom = e->mom; LA.vel = e->vel; LA.lo = e->lo; LA.hi = e->hi; LA.best = e->best;
-    LA.improved = e->improved; LA.sched = e->sched; LA.step = e->step; LA.grad_out = grad_out; LA.do_step = do_step;
+    LA.improved = e->improved; LA.sched = e->sched; LA.sched_len = e->cfg.num_iterations + 1; LA.step = e->step;
+    LA.grad_out = grad_out; LA.do_step = do_step;
     memcpy(LA.hyp, e->hyp, sizeof(LA.hyp));
     launch_analysis(LA, st);
     LAUNCHCHK(); PROF(K_ANALYSIS_ADJ);
@@ -841,11 +843,15 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
 
 extern "C" int aware_embed_iterate(aware_embed* e, int n_iters, void* stream) {
     if (!e || n_iters < 0) return AWARE_E_BADARG;
+    // the NAdam schedule table holds cfg.num_iterations steps (the reference's loop runs exactly that many,
+    // multibit_embedder.py:95): more than that since aware_embed_begin is a caller error
+    if (e->steps_done + n_iters > e->cfg.num_iterations) return AWARE_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     if (!e->cfg.use_graph) {
         for (int i = 0; i < n_iters; ++i) {
             int rc = embed_iteration(e, st, 1, nullptr);
             if (rc) return rc;
+            ++e->steps_done;
         }
         return AWARE_OK;
     }
@@ -870,21 +876,22 @@ extern "C" int aware_embed_iterate(aware_embed* e, int n_iters, void* stream) {
         }
     }
     int left = n_iters;
-    for (; left >= kGraphIters; left -= kGraphIters) HIPCHK(hipGraphLaunch(e->gexecN, st));
-    for (; left > 0; --left) HIPCHK(hipGraphLaunch(e->gexec, st));
+    for (; left >= kGraphIters; left -= kGraphIters) { HIPCHK(hipGraphLaunch(e->gexecN, st)); e->steps_done += kGraphIters; }
+    for (; left > 0; --left) { HIPCHK(hipGraphLaunch(e->gexec, st)); ++e->steps_done; }
     return AWARE_OK;
 }
 
 extern "C" int aware_embed_profile(aware_embed* e, int n_iters, int max_entries, float* ms_out, int* kind_out,
                                    void* stream) {
     if (!e || !ms_out || !kind_out || n_iters < 1) return AWARE_E_BADARG;
+    if (e->steps_done + n_iters > e->cfg.num_iterations) return AWARE_E_BADARG;      // as aware_embed_iterate
     hipStream_t st = (hipStream_t)stream;
     LaunchProfiler p;
     p.st = st;
     g_prof = &p;
     prof_mark(-1);
     int rc = AWARE_OK;
-    for (int i = 0; i < n_iters && rc == AWARE_OK; ++i) rc = embed_iteration(e, st, 1, nullptr);
+    for (int i = 0; i < n_iters && rc == AWARE_OK; ++i) { rc = embed_iteration(e, st, 1, nullptr); if (rc == AWARE_OK) ++e->steps_done; }
     g_prof = nullptr;
     hipError_t se = hipStreamSynchronize(st);
     int n = 0;

@@ -14,6 +14,8 @@
 //   modules/conv1d.py:38-42 (conv -> InstanceNorm1d -> LeakyReLU(0.2));
 //   modules/globalStandardize.py:16-21; modules/BRH.py:16-27;
 //   embedding/losses.py:38-42 (push_extremes) and :12-14,:23-25,:68-70.
+#include <mutex>
+
 #include "common.hpp"
 #include "kernels.h"
 
@@ -426,11 +428,8 @@ static void clip_launch(const float* A, int lda, const float* Bt, int ldb, const
 }
 
 // rows_per_clip = 32 * nwm (1..4).  epi: 0 plain, 1 forward IN+LeakyReLU, 2 backward of IN+LeakyReLU.
-// cfg: 4 (default) = bf16 matrix-pipe kernel with three-way operand split (gemm_x3.hip) wherever the shape allows,
-// else as 0; 0 = f32-MFMA kernel everywhere (BK 32, one LDS buffer, two-deep register prefetch)
-static int g_clip_cfg = 4;
-void set_gemm_clip_config(int cfg) { g_clip_cfg = cfg; }
-int get_gemm_clip_config() { return g_clip_cfg; }
+// The f32-MFMA kernel (BK 32, one LDS buffer, two-deep register prefetch): aware_embed_config.conv_pipe = 1 and the
+// shapes the bf16x3 kernel (gemm_x3.hip) does not serve.
 void launch_gemm_clip(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc, int B,
                       int nwm, int Tp, int N, int K, int epi, float* rstd_io, const float* act, hipStream_t st) {
 #define CL(M_, E_, K_, D_) clip_launch<M_, 4, E_, K_, D_>(A, lda, Bt, ldb, bias, C, ldc, B, Tp, N, K, rstd_io, act, st)
@@ -475,10 +474,13 @@ static void gemm_dispatch(int variant, const float* A, int lda, const float* Bt,
 #undef GL
 }
 
-// measured choice per shape (filled by gemm_autotune, e.g. from aware_embed_create)
+// measured choice per shape (filled by gemm_autotune, e.g. from aware_embed_create).  A memo only: every
+// configuration gives bit-identical results, so the cache never changes what a call computes; guarded by a
+// mutex so that sessions may be created from several host threads.
 struct GemmChoice { int M, N, K, variant; };
 static GemmChoice g_choice[64];
 static int g_nchoice = 0;
+static std::mutex g_choice_mu;
 
 static int gemm_heuristic(int M, int N, int K) {
     if (N <= 64) return 6;
@@ -487,6 +489,7 @@ static int gemm_heuristic(int M, int N, int K) {
     return (t >= 700) ? 10 : 4;
 }
 static int gemm_lookup(int M, int N, int K) {
+    std::lock_guard<std::mutex> lk(g_choice_mu);
     for (int i = 0; i < g_nchoice; ++i)
         if (g_choice[i].M == M && g_choice[i].N == N && g_choice[i].K == K) return g_choice[i].variant;
     return 0;
@@ -514,7 +517,10 @@ int gemm_autotune(const float* A, int lda, const float* Bt, int ldb, float* C, i
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    if (g_nchoice < 64) g_choice[g_nchoice++] = GemmChoice{M, N, K, best};
+    {
+        std::lock_guard<std::mutex> lk(g_choice_mu);
+        if (g_nchoice < 64) g_choice[g_nchoice++] = GemmChoice{M, N, K, best};
+    }
     return best;
 }
 
@@ -962,10 +968,12 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ a3,
         float L = wave_sum(lterm);
         if (c == 0) {
             loss_out[b] = L;
-            const float bl = best_loss[b];
-            const int imp = L < bl;
-            improved[b] = imp;
-            if (imp) best_loss[b] = L;
+            if (best_loss) {                                     // null: gradient-only call, no bookkeeping
+                const float bl = best_loss[b];
+                const int imp = L < bl;
+                improved[b] = imp;
+                if (imp) best_loss[b] = L;
+            }
             if (step && b == 0) *step += 1;
         }
         if (dA3 && c < nbits) {
@@ -1079,10 +1087,12 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ zpa
         const float L = wave_sum(lterm);
         if (c == 0) {
             loss_out[b] = L;
-            const float bl = best_loss[b];
-            const int imp = L < bl;
-            improved[b] = imp;
-            if (imp) best_loss[b] = L;
+            if (best_loss) {                                     // null: gradient-only call, no bookkeeping
+                const float bl = best_loss[b];
+                const int imp = L < bl;
+                improved[b] = imp;
+                if (imp) best_loss[b] = L;
+            }
             if (step && b == 0) *step += 1;
         }
         if (c < nbits) {

@@ -85,6 +85,7 @@ struct AnalysisArgs {
     float* best;
     const int* improved;              // [B]
     const float4* sched;              // per step {c_grad, c_mom, bias_correction2, 0}
+    int sched_len;                    // entries in `sched` (the step index is clamped to it)
     const int* step;                  // device step counter
     float* grad_out;                  // optional [NF][kFS] raw gradient (tests)
     int do_step;                      // 0: only write grad_out
@@ -196,7 +197,9 @@ __global__ __launch_bounds__(kThreads) void analysis_kernel(AnalysisArgs a) {
     float inv_bc2 = 1.f;
     int improved = 0;
     if (MODE == AN_ADJ && a.do_step) {
-        sc = a.sched[*a.step - 1];      // the read-out kernel of this iteration already advanced the counter
+        // the read-out kernel of this iteration already advanced the counter; clamped to the table (the C ABI
+        // refuses more than num_iterations steps, so the clamp only guards a misuse of the launcher)
+        sc = a.sched[min(max(*a.step - 1, 0), a.sched_len - 1)];
         inv_bc2 = 1.0f / sc.z;
         improved = a.improved[b];
     }
@@ -576,7 +579,7 @@ void launch_analysis(const AnalysisLaunch& L, hipStream_t st) {
     a.mag = L.mag; a.unit = (cf*)L.unit; a.full = (cf*)L.full;
     a.yraw = L.yraw; a.pdot = L.pdot; a.phasor = (const cf*)L.phasor;
     a.coef = L.coef; a.mom = L.mom; a.vel = L.vel; a.lo = L.lo; a.hi = L.hi; a.best = L.best;
-    a.improved = L.improved; a.sched = (const float4*)L.sched; a.step = L.step;
+    a.improved = L.improved; a.sched = (const float4*)L.sched; a.sched_len = L.sched_len > 0 ? L.sched_len : 1; a.step = L.step;
     a.grad_out = L.grad_out; a.do_step = L.do_step;
     a.hyp = make_float4(L.hyp[0], L.hyp[1], L.hyp[2], L.hyp[3]);
     int nx = (L.max_frames + kFramesPerWG - 1) / kFramesPerWG;

@@ -730,10 +730,12 @@ __global__ __launch_bounds__(512) void readout_x3_kernel(const float* __restrict
         const float L = wave_sum(lterm);
         if (g == 0 && lane == 0) {
             loss_out[clip] = L;
-            const float bl = best_loss[clip];
-            const int imp = L < bl;
-            improved[clip] = imp;
-            if (imp) best_loss[clip] = L;
+            if (best_loss) {                                     // null: gradient-only call, no bookkeeping
+                const float bl = best_loss[clip];
+                const int imp = L < bl;
+                improved[clip] = imp;
+                if (imp) best_loss[clip] = L;
+            }
             if (step && clip == 0) *step += 1;
         }
     }

@@ -32,6 +32,7 @@ struct AnalysisLaunch {
     const float* lo = nullptr; const float* hi = nullptr; float* best = nullptr;
     const int* improved = nullptr;
     const void* sched = nullptr;
+    int sched_len = 0;
     const int* step = nullptr;
     float* grad_out = nullptr;
     int do_step = 0;
@@ -78,8 +79,6 @@ int gemm_autotune(const float* A, int lda, const float* Bt, int ldb, float* C, i
 // clip-aligned GEMM with fused InstanceNorm+LeakyReLU epilogues (uniform batches, <= 128 pooled rows per clip)
 void launch_gemm_clip(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc, int B,
                       int nwm, int Tp, int N, int K, int epi, float* rstd_io, const float* act, hipStream_t st);
-void set_gemm_clip_config(int cfg);
-int get_gemm_clip_config();
 // ---- gemm_x3.hip: the same clip-aligned GEMM on the bf16 matrix pipe, f32-equivalent (3-way operand split) ----
 size_t x3_packed_bytes(int N, int K);
 void x3_pack(const float* Wt, int N, int K, uint16_t* out);      // host: [N][K] f32 -> fragment-ordered bf16 planes

@@ -13,20 +13,20 @@ import torch
 import torch.distributed as dist
 
 
-def init_distributed():
+def init_distributed(cpu_only: bool = False):
     """(rank, world_size, local_rank) from the torchrun environment; initialises the process
-    group when WORLD_SIZE > 1."""
+    group when WORLD_SIZE > 1 (RCCL on GPUs; gloo when there is no GPU or `cpu_only`, which never touches HIP)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    gpu = (not cpu_only) and torch.cuda.is_available()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if torch.cuda.is_available():
+        if gpu:
             torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    elif torch.cuda.is_available():
+        dist.init_process_group(backend="nccl" if gpu else "gloo", rank=rank, world_size=world)
+    elif gpu:
         torch.cuda.set_device(local_rank)
     return rank, world, local_rank
 

@@ -72,8 +72,9 @@ class WatermarkPipeline:
         return (vals > self.detector.threshold).to(torch.int32), vals
 
     def run(self, audio: "rt.Ragged", bits: torch.Tensor, input_rate: int | None = None, chains=None,
-            chain_of_clip=None, report_snr: bool = False, output_rate: int | None = None) -> PipelineResult:
-        res = self._run(audio, bits, input_rate, chains, chain_of_clip)
+            chain_of_clip=None, report_snr: bool = False, output_rate: int | None = None,
+            chains_by_kind=None) -> PipelineResult:
+        res = self._run(audio, bits, input_rate, chains, chain_of_clip, chains_by_kind)
         if report_snr:
             # imperceptibility metric of the reference (metrics/audio.py:68-89) on the device: watermarked clip
             # against the 16 kHz host clip over their common length
@@ -84,8 +85,33 @@ class WatermarkPipeline:
         self._host16k = None
         return res
 
+    def _apply_chains_staged(self, wm: "rt.Ragged", kinds_of_clip, factory) -> "rt.Ragged":
+        """Per-clip attack chains given as lists of attack KINDS (BASELINE config 5).  Stage s applies, for every
+        kind, ONE batched launch sequence to the clips whose chain has that kind at position s (at most
+        stages x kinds sub-batches however many distinct chains there are), so no workgroup branches on the attack
+        kind and the detector then runs once over all clips."""
+        cur = [wm.data[o:o + n] for o, n in zip(wm.offsets, wm.lengths)]
+        cache = self._sessions.setdefault(("attacks",), {})
+        depth = max((len(k) for k in kinds_of_clip), default=0)
+        for s in range(depth):
+            groups = {}
+            for i, k in enumerate(kinds_of_clip):
+                if s < len(k):
+                    groups.setdefault(k[s], []).append(i)
+            for kind in sorted(groups):
+                members = groups[kind]
+                if kind not in cache:
+                    cache[kind] = factory(kind)
+                parts = [cur[i] if cur[i].dtype == torch.float32 else cur[i].float() for i in members]
+                sub = rt.Ragged(torch.cat(parts) if len(parts) > 1 else parts[0].contiguous(), [int(p.numel()) for p in parts])
+                y = cache[kind].apply_batch(sub, self.sample_rate)
+                for i, o, n in zip(members, y.offsets, y.lengths):
+                    cur[i] = y.data[o:o + n]
+        parts = [c if c.dtype == torch.float32 else c.float() for c in cur]
+        return rt.Ragged(torch.cat(parts), [int(p.numel()) for p in parts])
+
     def _run(self, audio: "rt.Ragged", bits: torch.Tensor, input_rate: int | None = None, chains=None,
-             chain_of_clip=None) -> PipelineResult:
+             chain_of_clip=None, chains_by_kind=None) -> PipelineResult:
         """audio: ragged device clips at `input_rate` (default: the pipeline's 16 kHz);
         bits: device int tensor [B, n_bits] of 0/1.
         chains / chain_of_clip (BASELINE config 5): `chains` is a list of attack lists and
@@ -108,6 +134,12 @@ class WatermarkPipeline:
         clean_bits, clean_vals = self._detect_bits(wm)
         clean_err = (clean_bits != bits).sum()
         per = {}
+        if chains_by_kind is not None:
+            kinds_of_clip, factory = chains_by_kind
+            y = self._apply_chains_staged(wm, kinds_of_clip, factory)
+            det_bits, vals = self._detect_bits(y)
+            err = (det_bits != bits).sum()
+            return PipelineResult(det_bits, vals, err, clean_err, wm, per, seconds)
         if chains is not None:
             det_bits = torch.empty_like(clean_bits)
             vals = torch.empty_like(clean_vals)
@@ -161,3 +193,18 @@ def synthetic_clips(n_clips: int, seconds: float, rate: int, first_seed: int = 0
         audio[i] = 0.1 * torch.randn(n, generator=g, device=device)
         bits[i] = torch.randint(0, 2, (20,), generator=g, device=device, dtype=torch.int32)
     return rt.Ragged(audio.reshape(-1), [n] * n_clips), bits
+
+
+def synthetic_ragged_clips(seconds, rate: int, seeds=None, device="cuda"):
+    """Mixed-length variant (BASELINE config 5): clip i lasts seconds[i] s; seeded by seeds[i] (default: its index)."""
+    lengths = [int(round(float(sec) * rate)) for sec in seconds]
+    seeds = list(range(len(lengths))) if seeds is None else list(seeds)
+    audio = torch.empty(sum(lengths), dtype=torch.float32, device=device)
+    bits = torch.empty((len(lengths), 20), dtype=torch.int32, device=device)
+    o = 0
+    for i, (n, sd) in enumerate(zip(lengths, seeds)):
+        g = torch.Generator(device=device).manual_seed(1_000_003 * int(sd) + 17)
+        audio[o:o + n] = 0.1 * torch.randn(n, generator=g, device=device)
+        bits[i] = torch.randint(0, 2, (20,), generator=g, device=device, dtype=torch.int32)
+        o += n
+    return rt.Ragged(audio, lengths), bits

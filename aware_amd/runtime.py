@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import EmbedConfig, check, load_library, require_gpu
+from ._lib import AwareHipError, EmbedConfig, check, load_library, require_gpu
 
 SPEC_STRIDE = 256
 FULL_STRIDE = 520
@@ -189,13 +189,18 @@ class EmbedSession:
 
     def __init__(self, plan: Plan, det: DetectorWeights, batch: Batch, num_iterations=400, tolerance_db=6.0,
                  loss="push_extremes", lr=0.1, beta1=0.9, beta2=0.999, eps=1e-8, momentum_decay=4e-3,
-                 use_graph=True):
+                 use_graph=True, conv_pipe="bf16x3", fused_readout=True):
+        """conv_pipe: "bf16x3" (default: bf16 matrix pipe, exact three-way operand split) or "f32" (f32-input MFMA);
+        fused_readout=False selects the three-kernel read-out that ragged batches use (aware_embed_config)."""
         self.lib = load_library()
         self.plan, self.det, self.batch = plan, det, batch
         if loss not in LOSS_KINDS:
             raise ValueError(f"Unknown loss type: {loss}. Available on the HIP path: {list(LOSS_KINDS)}")
+        if conv_pipe not in ("bf16x3", "f32"):
+            raise ValueError(f"Unknown conv_pipe: {conv_pipe}")
         self.cfg = EmbedConfig(int(num_iterations), float(tolerance_db), LOSS_KINDS[loss], lr, beta1, beta2, eps,
-                               momentum_decay, int(bool(use_graph)))
+                               momentum_decay, int(bool(use_graph)), 0 if conv_pipe == "bf16x3" else 1,
+                               0 if fused_readout else 1)
         self.nbytes = self.lib.aware_embed_workspace_bytes(batch.h, det.h)
         self.ws = torch.empty(self.nbytes, dtype=torch.uint8, device=_dev())
         h = C.c_void_p()
@@ -216,7 +221,10 @@ class EmbedSession:
         check(self.lib.aware_embed_begin(self.h, _ptr(audio), _ptr(self._target), _stream()), "aware_embed_begin")
 
     def iterate(self, n: int):
-        check(self.lib.aware_embed_iterate(self.h, int(n), _stream()), "aware_embed_iterate")
+        rc = self.lib.aware_embed_iterate(self.h, int(n), _stream())
+        if rc == -1:
+            raise ValueError(f"iterate({n}): more than num_iterations = {self.cfg.num_iterations} steps since begin()")
+        check(rc, "aware_embed_iterate")
 
     def gradient(self) -> torch.Tensor:
         g = torch.zeros((self.batch.total_frames, SPEC_STRIDE), dtype=torch.float32, device=self.ws.device)
@@ -273,11 +281,6 @@ def gemm_nt(a: torch.Tensor, bt: torch.Tensor, bias: torch.Tensor | None = None)
     check(lib.aware_gemm_nt(_ptr(a), a.stride(0), _ptr(bt), bt.stride(0), _ptr(bias), _ptr(c), N, M, N, K, _stream()),
           "aware_gemm_nt")
     return c
-
-
-def tune(key: int, value: int) -> None:
-    """Development knob (aware_tune in the header): key 1 selects the kernel of the clip-aligned conv blocks."""
-    check(load_library().aware_tune(int(key), int(value)), "aware_tune")
 
 
 def x3_pack(wt: torch.Tensor) -> torch.Tensor:

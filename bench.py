@@ -1,32 +1,41 @@
 #!/usr/bin/env python3
 """Headline benchmark: waveform-seconds/sec through embed -> attack -> detect on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload config3]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A step is one pass of the hot path over one batch of synthetic clips per GPU: 44.1 kHz sigma=0.1
-Gaussian clips (already resident in HBM) -> polyphase 160/441 -> per-clip 400-iteration embed ->
-(attack stack) -> detect -> bit errors.  Workloads (BASELINE.json configs):
-    config1 (default): 64 x 3 s clips per GPU, clean embed -> detect
-    config2:           256 x 3 s clips per GPU, full attack stack (resample, lowpass, noise, PCM)
-Clips shard by global index across ranks (weak scaling, no data-path collective); the only
-collectives are a SUM of the counters and a MAX of the wall time.  Rank 0 prints ONE JSON line.
+A step is one pass of the hot path over one batch of synthetic clips per GPU: 44.1 kHz sigma = 0.1 Gaussian
+clips (already resident in HBM) -> polyphase 160/441 -> per-clip 400-iteration embed -> attack stage -> detect ->
+bit errors (the loop of the reference's harness, scripts/test.py:52-106).  Workloads are named after
+BASELINE.json's configs:
+    config3 (default): 256 x 3 s clips per GPU, full attack stack [resample 16k<->44.1k, lowpass, gaussian 20 dB,
+                       pcm16] -- the largest single-GPU configuration, the one the metric is quoted on
+    config2:           64 x 3 s clips per GPU, clean embed -> detect
+    config4:           config3's per-GPU batch on every rank (8 GPUs: 2048 clips); the same code path as config3
+    config5:           256 x N clips of seeded 1..10 s with a seeded attack chain per clip drawn from {pcm, resample,
+                       lowpass, bandstop, cut, noise}; clips are assigned to ranks by frame count (shard_by_cost)
+    stub:              no GPU work at all (CPU tests of the launcher and the collectives)
+Clips shard by global index across ranks (weak scaling, no data-path collective); the only collectives are a SUM of
+the counters and a MAX of the wall time.  Rank 0 prints ONE JSON line.
+
+`--gpus N` without a torchrun environment starts N child ranks itself (one process per GPU) BEFORE anything
+touches the GPU; the parent only waits for them.  A world size that differs from --gpus is an error.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: dense f32-input MFMA peak
 MFMA_BF16_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak
+WORKLOADS = ["config2", "config3", "config4", "config5", "stub"]
+CONFIG5_KINDS = ["pcm", "resample", "lowpass", "bandstop", "cut", "noise"]
 
 
 def detector_flops_per_clip_iter(T):
@@ -39,55 +48,138 @@ def dsp_bytes_per_clip_iter(T):
     return 28500 * T - 6144
 
 
-def cpu_baseline(seconds_budget=20.0):
-    """The CPU oracle (a restatement of the reference's torch-CPU path, kind "port") timed on this
-    host on a bounded sample: ONE 3 s clip, as many of the 400 iterations as fit the budget
-    (work per iteration is constant, so the full embed is extrapolated), plus one detect."""
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+# ---------------------------------------------------------------------------------------------------
+# launcher: one process per GPU
+# ---------------------------------------------------------------------------------------------------
+def spawn_ranks(n, argv):
+    """Start n copies of this script as ranks 0..n-1 (torchrun-style environment) and wait.  Called before any GPU
+    call: the parent never initialises HIP.  Returns the worst exit code."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------
+# workloads
+# ---------------------------------------------------------------------------------------------------
+def config5_plan(per_gpu, world):
+    """Seeded description of BASELINE config 5 for `world` ranks: per_gpu*world clips, duration ~ U{1..10 s},
+    per-clip chain = random subset (1..3 kinds) in random order of CONFIG5_KINDS.  Returns (seconds[], chains[])."""
+    import numpy as np
+    rng = np.random.default_rng(20250905)
+    n = per_gpu * world
+    secs = rng.integers(1, 11, n).tolist()
+    chains = []
+    for _ in range(n):
+        k = int(rng.integers(1, 4))
+        chains.append([CONFIG5_KINDS[j] for j in rng.permutation(len(CONFIG5_KINDS))[:k]])
+    return secs, chains
+
+
+def make_attack_of_kind(kind):
+    from aware_amd import attacks as A
+    return {"pcm": lambda: A.PCMBitDepthConversion(16), "resample": lambda: A.Resample(),
+            "lowpass": lambda: A.LowPassFilter(), "bandstop": lambda: A.RandomBandstop(),
+            "cut": lambda: A.DeleteSamples(0.1), "noise": lambda: A.GaussianNoise(20.0)}[kind]()
+
+
+def cpu_baseline(workload):
+    """The CPU oracle (a restatement of the reference's torch-CPU path, kind "port") timed on this host on a bounded
+    sample of the same workload: ONE 3 s clip through front end -> embed -> attack stack -> detect, with as many of
+    the 400 embed iterations as fit the budget (work per iteration is constant, so the full embed is extrapolated)."""
+    import numpy as np
+    import torch
     from oracle import aware_oracle as O
-    # the GPU box gives one GPU's share of the host: 16 cores (never the machine's full count)
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(16, avail))
+    cores = max(1, min(16, avail))      # the GPU box gives one GPU's share of the host: 16 cores
     torch.set_num_threads(cores)
     rng = np.random.default_rng(0)
-    audio = (0.1 * rng.standard_normal(48000)).astype(np.float32)
+    x44 = (0.1 * rng.standard_normal(132300)).astype(np.float32)
     wm = (2 * rng.integers(0, 2, 20) - 1).astype(np.float32)
+    t0 = time.time()
+    audio = O.resample_poly(x44, 160, 441).astype(np.float32)           # scripts/test.py:60-63
+    t_front = time.time() - t0
     iters = 40
     emb = O.Embedder(num_iterations=iters)
     emb.embed(audio[None], wm[None])                       # warm-up (thread pools, allocator)
     t0 = time.time()
     y, _ = emb.embed(audio[None], wm[None])
     t_emb = time.time() - t0
-    t1 = time.time()
-    emb.detect_raw(y.numpy())
-    t_det = time.time() - t1
+    y = y[0].numpy()
+    t_att = 0.0
+    if workload != "config2":
+        t0 = time.time()
+        y = O.resample_attack(y, 16000, 16000)
+        y = O.lowpass_attack(y, 16000)
+        y = O.gaussian_noise_attack(np.asarray(y, dtype=np.float32), 20.0, 0)
+        y = O.pcm_bit_depth(y, 16)
+        t_att = time.time() - t0
+    t0 = time.time()
+    emb.detect_raw(np.asarray(y, dtype=np.float32)[None])
+    t_det = time.time() - t0
     per_iter = t_emb / iters
-    full = per_iter * 400 + t_det
+    full = t_front + per_iter * 400 + t_att + t_det
     return {"value": 3.0 / full, "unit": "waveform-seconds/sec", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": f"1 x 3 s clip @16 kHz, {iters} of 400 embed iterations timed ({per_iter*1e3:.1f} ms/iter, "
-                      f"extrapolated x400) + 1 detect ({t_det*1e3:.1f} ms); vectorised bounds (no 1.3 s/clip Python loop)"}
+            "sample": f"1 x 3 s clip: front end {t_front*1e3:.0f} ms + {iters} of 400 embed iterations timed "
+                      f"({per_iter*1e3:.1f} ms/iter, extrapolated x400) + attack stack {t_att*1e3:.0f} ms + 1 detect "
+                      f"({t_det*1e3:.1f} ms); vectorised bounds (no 1.3 s/clip Python loop)"}
 
 
 def pmc_traffic_per_launch(per_gpu):
-    """Mean HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/, same kernels and
-    batch; bench.py cannot collect PMC counters itself).  One row of the profile = one launch per iteration.
-    Returns (bytes, source) or (None, None) when no profile of this batch size is present."""
+    """Mean HBM bytes per launch of the dominant kernel from the PMC passes stored under profiles/ (same command, same
+    batch; separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs -- bench.py cannot collect counters itself).
+    Returns (bytes, source) or (None, None) when no stored pass matches this batch size."""
     import csv
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic_pmc.csv")
-    if not os.path.exists(path):
-        return None, None
-    with open(path) as f:
-        rows = [r for r in csv.reader(l for l in f if not l.startswith("#"))][1:]
-    sel = [float(r[3]) + float(r[4]) for r in rows if int(r[0]) == per_gpu and "gemm_clip_x3_kernel<3," in r[1]]
-    if len(sel) != 5:
-        return None, None
-    return sum(sel) / len(sel) * 1048576.0, "profiles/r01_hbm_traffic_pmc.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 fetch x2 correction)"
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_pmc.csv")), reverse=True):
+        with open(path) as f:
+            rows = [r for r in csv.reader(l for l in f if not l.startswith("#"))][1:]
+        sel = [float(r[3]) + float(r[4]) for r in rows if int(r[0]) == per_gpu and "gemm_clip_x3_kernel<3," in r[1]]
+        if len(sel) == 5:
+            rel = os.path.relpath(path, ROOT)
+            return sum(sel) / len(sel) * 1048576.0, (f"stored profile {rel} of this workload (rocprofv3 --pmc FETCH_SIZE / "
+                                                     "WRITE_SIZE passes, gfx950 fetch x2 correction); not re-measured in this run")
+    return None, None
 
 
-def log(*a):
-    print("[bench]", *a, file=sys.stderr, flush=True)
+def run_stub(args, rank, world):
+    """No GPU: the launcher, the barrier and the reductions only (tests/test_bench_launcher.py)."""
+    from aware_amd import parallel
+    parallel.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.01)
+    parallel.barrier()
+    wall = time.perf_counter() - t0
+    sums, maxes = parallel.reduce_metrics({"seconds": 3.0 * args.steps, "ranks": 1}, {"wall": wall}, device="cpu")
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": sums["seconds"] / maxes["wall"], "unit": "waveform-seconds/sec",
+                          "n_gpus": world, "ranks_seen": int(sums["ranks"]), "steps": args.steps, "warmup": args.warmup,
+                          "config": {"workload": "stub"}}))
+    return 0
 
 
 def main():
@@ -95,35 +187,72 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="config1", choices=["config1", "config2"])
+    ap.add_argument("--workload", default="config3", choices=WORKLOADS)
     ap.add_argument("--clips-per-gpu", type=int, default=0)
     ap.add_argument("--seconds", type=float, default=3.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass (roofline = null)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no torchrun environment: become the launcher (nothing has touched the GPU in this process)
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     from aware_amd import parallel
-    rank, world, local_rank = parallel.init_distributed()
+    rank, world, local_rank = parallel.init_distributed(cpu_only=args.workload == "stub")
+    if world != args.gpus:
+        log(f"world size {world} (WORLD_SIZE) differs from --gpus {args.gpus}")
+        sys.exit(2)
+    if args.workload == "stub":
+        sys.exit(run_stub(args, rank, world))
+
+    import numpy as np
+    import torch
     from aware_amd._lib import require_gpu
     require_gpu()
     from aware_amd import runtime as rt
     from aware_amd.utils.models import load
-    from aware_amd.pipeline import WatermarkPipeline, synthetic_clips
-    from aware_amd.attacks import config3_attack_stack
+    from aware_amd.pipeline import WatermarkPipeline, synthetic_clips, synthetic_ragged_clips
+    from aware_amd.attacks import config3_attack_stack, resample_poly_batch
 
     dev = torch.device("cuda", torch.cuda.current_device())
-    per_gpu = args.clips_per_gpu or (64 if args.workload == "config1" else 256)
-    attacks = [] if args.workload == "config1" else config3_attack_stack()
+    wl = args.workload
+    per_gpu = args.clips_per_gpu or (64 if wl == "config2" else 256)
+    attacks = [] if wl == "config2" else config3_attack_stack()
     embedder, detector = load()
     embedder.use_graph = not args.no_graph
-    pipe = WatermarkPipeline(embedder, detector, attacks, sample_rate=16000, attack_mode="chain")
-    audio, bits = synthetic_clips(per_gpu, args.seconds, 44100, first_seed=rank * per_gpu, device=dev)
-
-    n16 = -(-int(round(args.seconds * 44100)) * 160 // 441)        # clip length after the 44.1k -> 16k front end
-    pipe.prepare([n16] * per_gpu, input_rate=44100)                # set-up (tables, tile choice, graphs), not a step
-    log(f"rank {rank}/{world}: {per_gpu} clips x {args.seconds} s resident on {dev}; warm-up x{args.warmup}")
+    run_kw = {"input_rate": 44100}
+    if wl == "config5":
+        secs_all, chains_all = config5_plan(per_gpu, world)
+        frames = [1 + (-(-s * 44100 * 160 // 441)) // 256 for s in secs_all]
+        mine = parallel.shard_by_cost(frames, world)[rank]           # balance the sum of frame counts per rank
+        mine.sort(key=lambda i: (-frames[i], i))                     # longest first inside the rank
+        secs = [secs_all[i] for i in mine]
+        pipe = WatermarkPipeline(embedder, detector, [], sample_rate=16000)
+        audio, bits = synthetic_ragged_clips(secs, 44100, seeds=mine, device=dev)
+        run_kw["chains_by_kind"] = ([chains_all[i] for i in mine], make_attack_of_kind)
+        n16 = [-(-n * 160 // 441) for n in audio.lengths]
+        clip_seconds = float(np.mean(secs))
+        desc = (f"config5: {len(mine)} clips/GPU of seeded 1..10 s (mean {clip_seconds:.2f} s) @44.1 kHz -> 16 kHz, embed(400 it) -> "
+                "seeded chain of 1..3 of {pcm16, resample, lowpass, bandstop, cut 10 %, gaussian 20 dB} per clip -> detect")
+    else:
+        pipe = WatermarkPipeline(embedder, detector, attacks, sample_rate=16000, attack_mode="chain")
+        audio, bits = synthetic_clips(per_gpu, args.seconds, 44100, first_seed=rank * per_gpu, device=dev)
+        n16 = [-(-int(round(args.seconds * 44100)) * 160 // 441)] * per_gpu   # clip length after the 44.1k -> 16k front end
+        clip_seconds = args.seconds
+        if wl == "config2":
+            desc = "config2: %d x %.0f s clips/GPU @44.1 kHz -> 16 kHz, clean embed(400 it) -> detect" % (per_gpu, args.seconds)
+        else:
+            desc = ("%s: %d x %.0f s clips/GPU @44.1 kHz -> 16 kHz, embed(400 it) -> [resample 16k<->44.1k, lowpass, "
+                    "gaussian 20 dB, pcm16] -> detect" % (wl if wl == "config4" or world == 1 else "config4 (config3 per GPU)",
+                                                          per_gpu, args.seconds))
+    pipe.prepare(n16, input_rate=44100)                              # set-up (tables, tile choice, graphs), not a step
+    log(f"rank {rank}/{world}: {len(n16)} clips ({sum(audio.lengths) / 44100.0:.0f} waveform-s) resident on {dev}; warm-up x{args.warmup}")
     for _ in range(args.warmup):
-        res = pipe.run(audio, bits, input_rate=44100)
+        res = pipe.run(audio, bits, **run_kw)
     torch.cuda.synchronize()
     log("timed region starts")
     parallel.barrier()
@@ -131,28 +260,30 @@ def main():
     t0 = time.perf_counter()
     errs = torch.zeros((), dtype=torch.int64, device=dev)
     clean = torch.zeros((), dtype=torch.int64, device=dev)
-    secs = 0.0
+    secs_done = 0.0
     for _ in range(args.steps):
-        res = pipe.run(audio, bits, input_rate=44100)
+        res = pipe.run(audio, bits, **run_kw)
         errs += res.bit_errors
         clean += res.clean_bit_errors
-        secs += res.seconds
+        secs_done += res.seconds
     torch.cuda.synchronize()
     parallel.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     log(f"timed region done: {wall:.3f} s for {args.steps} steps")
     sums, maxes = parallel.reduce_metrics(
-        {"bit_errors": int(errs), "clean_bit_errors": int(clean), "bits": args.steps * per_gpu * 20, "seconds": secs},
+        {"bit_errors": int(errs), "clean_bit_errors": int(clean), "bits": args.steps * len(n16) * 20, "seconds": secs_done},
         {"wall": wall}, device=dev)
 
-    # ---- roofline of the dominant kernel (fp32 MFMA GEMM), measured live with HIP events on the
-    # launch stream: 3 eager loop bodies through aware_embed_profile ---------------------------
+    # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream: 3 eager loop bodies
+    # through aware_embed_profile on a freshly begun session (the optimiser steps count against num_iterations) ----
     roof = None
     breakdown = {}
-    if rank == 0:
+    if rank == 0 and not args.no_profile:
         key = next(k for k in pipe._sessions if not (isinstance(k[0], str)))
         batch, sess = pipe._sessions[key]
+        x16 = resample_poly_batch(audio, 16000, 44100)
+        sess.begin(x16.data, (2 * bits - 1).to(torch.float32))
         n_it = 3
         prof = rt.embed_profile(sess, n_it)
         for kind, ms in prof:
@@ -165,7 +296,9 @@ def main():
         all_ms = sum(breakdown[k][0] for k in gemm_kinds)
         all_n = sum(breakdown[k][1] for k in gemm_kinds)
         flops_iter = sum(detector_flops_per_clip_iter(t) for t in batch.frames)
-        peak, peak_note = MFMA_F32_PEAK_TF, "dense f32-input MFMA peak"
+        peak = MFMA_BF16_PEAK_TF / 6.0
+        peak_note = ("f32-equivalent peak of the bf16x3 kernel: dense bf16 MFMA peak (2.5 PFLOP/s) / 6 bf16 partial products "
+                     "per f32 multiply-add")
         if "gemm_x3_fwd" in breakdown:
             # dominant kernel: the clip-aligned conv block on the bf16 matrix pipe (gemm_x3.hip), 5 launches per
             # iteration: conv0..2 forward (K = 128, 512, 1024) and the data gradients of conv2, conv1 (K = 1024);
@@ -173,32 +306,17 @@ def main():
             fl = 2.0 * rows * (ch[0] * ch[1] + ch[1] * ch[2] + ch[2] * ch[3]) + 2.0 * rows * (ch[3] * ch[2] + ch[2] * ch[1])
             ms = breakdown["gemm_x3_fwd"][0] + breakdown["gemm_x3_bwd"][0]
             nl = breakdown["gemm_x3_fwd"][1] + breakdown["gemm_x3_bwd"][1]
-            rg = (rows // len(batch.frames) + 31) // 32          # 32-row groups per clip
-            name = f"aware::gemm_clip_x3_kernel<{rg},EPI,8> (forward EPI=1 x2 and EPI=3 x1, backward EPI=2 x2 per iteration)"
-            per_kernel = {f"gemm_clip_x3_kernel<{rg},1|3,8>": round(breakdown["gemm_x3_fwd"][0] * 1e3 / breakdown["gemm_x3_fwd"][1], 2),
-                          f"gemm_clip_x3_kernel<{rg},2,8>": round(breakdown["gemm_x3_bwd"][0] * 1e3 / breakdown["gemm_x3_bwd"][1], 2)}
-            peak = MFMA_BF16_PEAK_TF / 6.0
-            peak_note = ("f32-equivalent peak of this kernel: dense bf16 MFMA peak (2.5 PFLOP/s) / 6 bf16 partial products per "
-                         "f32 multiply-add")
-        elif "gemm_clip_fwd" in breakdown:
-            # f32-MFMA clip-aligned GEMM (aware_tune(1, 0)): 3 forward + 3 backward launches per iteration
-            fl = 2.0 * rows * (ch[0] * ch[1] + ch[1] * ch[2] + ch[2] * ch[3]) + 2.0 * rows * (ch[4] * ch[3] + ch[3] * ch[2] + ch[2] * ch[1])
-            ms = breakdown["gemm_clip_fwd"][0] + breakdown["gemm_clip_bwd"][0]
-            nl = breakdown["gemm_clip_fwd"][1] + breakdown["gemm_clip_bwd"][1]
-            name = "aware::gemm_clip_kernel<3,4,EPI,32,1> (EPI=1 forward x3, EPI=2 backward x3 per iteration)"
-            per_kernel = {"gemm_clip_kernel<.,.,1,.,.>": round(breakdown["gemm_clip_fwd"][0] * 1e3 / breakdown["gemm_clip_fwd"][1], 2),
-                          "gemm_clip_kernel<.,.,2,.,.>": round(breakdown["gemm_clip_bwd"][0] * 1e3 / breakdown["gemm_clip_bwd"][1], 2)}
+            name = "aware::gemm_clip_x3_kernel<RG,EPI,8> (forward EPI=1 x2 and EPI=3 x1, backward EPI=2 x2 per iteration)"
+            per_kernel = {"gemm_clip_x3_kernel<.,1|3,8>": round(breakdown["gemm_x3_fwd"][0] * 1e3 / breakdown["gemm_x3_fwd"][1], 2),
+                          "gemm_clip_x3_kernel<.,2,8>": round(breakdown["gemm_x3_bwd"][0] * 1e3 / breakdown["gemm_x3_bwd"][1], 2)}
         else:
             fl, ms, nl = flops_iter, all_ms, all_n
             name = ("aware::gemm_clip_x3_kernel<1,0,8> on 32-row blocks (+ gemm_nt_kernel for shapes it does not serve): "
                     "all detector GEMMs of the iteration, generic path")
             per_kernel = {"gemm_clip_x3_kernel<1,0,8>|gemm_nt_kernel": round(all_ms * 1e3 / all_n, 2)}
-            if os.environ.get("AWARE_TUNE_CLIP", "4") == "4":
-                peak = MFMA_BF16_PEAK_TF / 6.0
-                peak_note = ("f32-equivalent peak of the bf16x3 kernel: dense bf16 MFMA peak (2.5 PFLOP/s) / 6 bf16 partial "
-                             "products per f32 multiply-add")
         achieved = fl * n_it / (ms * 1e-3) / 1e12
-        dsp_ms = sum(breakdown[k][0] for k in ("synth", "analysis", "synth_adjoint", "analysis_adjoint_nadam"))
+        dsp_kinds = ("synth", "analysis", "synth_adjoint", "analysis_adjoint_nadam")
+        dsp_ms = sum(breakdown[k][0] for k in dsp_kinds)
         dsp_bytes = sum(dsp_bytes_per_clip_iter(t) for t in batch.frames) * n_it
         roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": round(peak, 1),
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None, "peak_note": peak_note,
@@ -211,17 +329,17 @@ def main():
                                        "note": "SURVEY 8(d) algorithmic detector flops / time of every GEMM launch"},
                 "dsp_hbm": {"bound": "hbm", "achieved": round(dsp_bytes / (dsp_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": round(dsp_bytes / (dsp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                            "avg_launch_us": round(dsp_ms * 1e3 / (4 * n_it), 2)}}
-
+                            "avg_launch_us": round(dsp_ms * 1e3 / (4 * n_it), 2),
+                            "algorithmic_bytes_per_iteration": dsp_bytes // n_it}}
         if "gemm_x3_fwd" in breakdown and len(set(batch.frames)) == 1:
             tb, src = pmc_traffic_per_launch(len(batch.frames))
             if tb is not None:
                 roof["traffic"], roof["traffic_source"] = round(tb), src
-                # operands of the five launches: A rows (f32) + output rows (f32) + packed weights (3 x bf16), and the
-                # forward activation re-read by the two backward epilogues
-                pairs = [(ch[0], ch[1]), (ch[1], ch[2]), (ch[2], ch[3]), (ch[3], ch[2]), (ch[2], ch[1])]
-                alg = sum(4.0 * rows * (k + n) + 6.0 * k * n for k, n in pairs) + 4.0 * rows * (ch[2] + ch[1])
-                roof["algorithmic_bytes_per_launch"] = round(alg / 5)
+            # operands of the five launches: A rows (f32) + output rows (f32) + packed weights (3 x bf16), and the
+            # forward activation re-read by the two backward epilogues
+            pairs = [(ch[0], ch[1]), (ch[1], ch[2]), (ch[2], ch[3]), (ch[3], ch[2]), (ch[2], ch[1])]
+            alg = sum(4.0 * rows * (k + n) + 6.0 * k * n for k, n in pairs) + 4.0 * rows * (ch[2] + ch[1])
+            roof["algorithmic_bytes_per_launch"] = round(alg / 5)
     if world > 1:
         import torch.distributed as dist
         parallel.barrier()
@@ -233,15 +351,12 @@ def main():
         "metric": "waveform-seconds/sec through embed->attack->detect; BER vs reference",
         "value": round(value, 2), "unit": "waveform-seconds/sec", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(maxes["wall"] / args.steps * 1e3, 2), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "arithmetic": ("f32 throughout; the detector's conv blocks multiply on the bf16 matrix pipe with every f32 operand split "
-                       "exactly into three bf16 terms (six partial products per multiply-add, f32 accumulation): measured error "
-                       "vs fp64 at or below the f32-MFMA chain's (tests/test_gpu_kernels.py::test_gemm_clip_x3)"
-                       if os.environ.get("AWARE_TUNE_CLIP", "4") == "4" else "f32 throughout (f32-input MFMA)"),
-        "config": {"workload": ("config1: %d x %.0f s clips/GPU @44.1 kHz -> 16 kHz, clean embed(400 it)->detect" if not attacks
-                                else "config2: %d x %.0f s clips/GPU @44.1 kHz -> 16 kHz, embed(400 it) -> "
-                                     "[resample 16k<->44.1k, lowpass, gaussian 20 dB, pcm16] -> detect") % (per_gpu, args.seconds),
-                   "clips_per_gpu": per_gpu, "clip_seconds": args.seconds, "iterations": embedder.num_iterations,
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (detector GEMMs on the bf16 MFMA pipe with every f32 operand split exactly into 3 bf16 terms, 6 partial "
+                 "products, f32 accumulate: f32-equivalent)",
+        "data": "synthetic",
+        "config": {"workload": desc, "clips_per_gpu": len(n16), "clip_seconds": clip_seconds,
+                   "iterations": embedder.num_iterations,
                    "parallelism": f"dp{world} (shard by clip, no data-path collective)", "hip_graph": not args.no_graph},
         "ber_percent": round(100.0 * sums["bit_errors"] / sums["bits"], 4),
         "ber_percent_clean": round(100.0 * sums["clean_bit_errors"] / sums["bits"], 4),
@@ -250,7 +365,7 @@ def main():
     }
     if world == 1 and not args.no_cpu_baseline:
         log("timing the CPU oracle on a bounded sample (about 10-30 s)")
-        out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline"] = cpu_baseline(wl)
     print(json.dumps(out))
 
 

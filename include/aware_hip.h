@@ -45,15 +45,13 @@ typedef struct aware_detector aware_detector;
 typedef struct aware_batch aware_batch;
 typedef struct aware_embed aware_embed;
 
+/* ABI version (200: no process-global knobs; the kernel choices live in aware_embed_config) */
 int aware_version(void);
+/* text of the last failed HIP runtime call on the calling thread (thread-local) */
 const char* aware_last_hip_error(void);
-/* development knobs, not part of the drop-in surface.
- * key 1 = kernel of the clip-aligned conv blocks.  4 [default]: bf16 matrix pipe, operands split exactly into three
- * bf16 terms, six partial products per multiply-add, f32 accumulation (f32-equivalent accuracy; csrc/gemm_x3.hip) for
- * K % 64 == 0, N % 128 == 0, f32 MFMA otherwise.  0: f32 MFMA everywhere (the pipe the bf16 kernel is tested against).
- * key 2 = fused read-out kernel of the embed loop on uniform batches (1 [default] / 0: split-K GEMM + tail kernel +
- * data-gradient GEMM, the path ragged batches always take). */
-int aware_tune(int key, int value);
+/* The library keeps no mutable process-global state: handles are independent, every entry point may be called
+ * from any host thread on any stream (one thread at a time per handle).  The only shared object is a mutex-guarded
+ * memo of measured GEMM tile choices, which never changes a result (all tile configurations are bit-identical). */
 
 /* ---- plan: FFT twiddles, window, band ------------------------------------------------
  * Replaces the constructor state of STFT / ISTFT (src/AWARE/utils/audio/stft.py:14-25,
@@ -125,6 +123,15 @@ typedef struct aware_embed_config {
     int loss;                /* 0 = push_extremes */
     float lr, beta1, beta2, eps, momentum_decay;   /* 0.1, 0.9, 0.999, 1e-8, 4e-3 */
     int use_graph;           /* 1: capture one iteration into a hipGraph and replay it */
+    /* kernel choices of this session (zero = default).
+     * conv_pipe 0: the detector's GEMMs run on the bf16 matrix pipe with every f32 operand split exactly into three
+     *   bf16 terms, six partial products per multiply-add, f32 accumulation (f32-equivalent accuracy;
+     *   csrc/gemm_x3.hip) wherever K % 64 == 0 and N % 128 == 0, f32 MFMA otherwise.
+     * conv_pipe 1: f32-input MFMA everywhere (the pipe the bf16 kernel is tested against).
+     * readout 0: fused read-out kernel on uniform batches; 1: split-K GEMM + tail kernel + data-gradient GEMM (the
+     *   path ragged batches take). */
+    int conv_pipe;
+    int readout;
 } aware_embed_config;
 
 size_t aware_embed_workspace_bytes(const aware_batch* batch, const aware_detector* det);
@@ -136,16 +143,19 @@ void aware_embed_destroy(aware_embed* e);
  * [B][n_bits] bipolar (+-1), PatternEncoder output (utils/watermark/encoder.py:35-45). */
 int aware_embed_begin(aware_embed* e, const float* audio, const float* target, void* stream);
 /* n_iters loop bodies (:95-122): synth -> normalise -> analysis -> detector fwd -> loss ->
- * backward -> NAdam -> clamp -> best snapshot.  No host synchronisation. */
+ * backward -> NAdam -> clamp -> best snapshot.  No host synchronisation.  AWARE_E_BADARG when more than
+ * cfg.num_iterations steps would have run since aware_embed_begin (the reference's loop runs exactly that many). */
 int aware_embed_iterate(aware_embed* e, int n_iters, void* stream);
-/* forward + backward without the optimiser step; grad: dev f32 [total frames][256] = dL/dcoef */
+/* forward + backward without the optimiser step and without best-loss bookkeeping; grad: dev f32
+ * [total frames][256] = dL/dcoef; loss[] and pred[] (aware_embed_buffer 0, 2) are refreshed */
 int aware_embed_gradient(aware_embed* e, float* grad, void* stream);
 /* Timing aid for the roofline report: runs n_iters loop bodies eagerly with a HIP event recorded on
  * `stream` after every kernel launch; writes the elapsed milliseconds between consecutive events and
  * a kernel kind per launch (0 synth, 1 analysis, 2 generic gemm, 3 mel-norm, 4 in+lrelu, 5 read-out/tail,
  * 6 synth adjoint, 7 analysis adjoint + NAdam, 8 misc, 9 clip-aligned gemm with fused forward
  * epilogue, 10 the same with fused backward epilogue).  Synchronises the stream.  Returns the number of
- * entries written or a negative error.  (These iterations DO step the optimiser.) */
+ * entries written or a negative error.  (These iterations DO step the optimiser and count against
+ * cfg.num_iterations like aware_embed_iterate.) */
 int aware_embed_profile(aware_embed* e, int n_iters, int max_entries, float* ms_out, int* kind_out, void* stream);
 /* final synthesis from the best coefficients (:173-194) and the service-level rescale
  * (service/embed.py:69,73): out[b] = rescale[b] * normalise(istft(...)).  rescale: dev f32 [B] or NULL. */

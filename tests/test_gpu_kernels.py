@@ -332,16 +332,12 @@ def test_first_iteration_x3_vs_f32_pipe(rt, plan, det, O):
     wm = np.stack([O.bits_to_bipolar(p[1]) for p in pairs]).astype(np.float32)
     batch = rt.Batch(lengths)
     res = []
-    try:
-        for cfg in (4, 0):
-            rt.tune(1, cfg)
-            sess = rt.EmbedSession(plan, det, batch, use_graph=False)
-            sess.begin(batch.pack([p[0] for p in pairs]), torch.from_numpy(wm).cuda())
-            g = sess.gradient()
-            torch.cuda.synchronize()
-            res.append((g.cpu().double(), sess.loss.cpu().numpy().copy(), sess.pred.cpu().numpy().copy()))
-    finally:
-        rt.tune(1, 4)
+    for pipe in ("bf16x3", "f32"):
+        sess = rt.EmbedSession(plan, det, batch, use_graph=False, conv_pipe=pipe)
+        sess.begin(batch.pack([p[0] for p in pairs]), torch.from_numpy(wm).cuda())
+        g = sess.gradient()
+        torch.cuda.synchronize()
+        res.append((g.cpu().double(), sess.loss.cpu().numpy().copy(), sess.pred.cpu().numpy().copy()))
     (g4, l4, p4), (g0, l0, p0) = res
     assert np.max(np.abs(l4 - l0)) < 2e-6
     assert np.max(np.abs(p4 - p0)) < 2e-6
@@ -353,7 +349,7 @@ def test_first_iteration_x3_vs_f32_pipe(rt, plan, det, O):
 @pytest.mark.parametrize("n", [16000, 48000, 33000, 64000])
 def test_fused_readout_vs_three_kernel_path(rt, plan, det, O, n):
     """Uniform batches run the last conv block, BRH, loss, their backward and the last data gradient in
-    readout_x3_kernel (fed by split-K partials from the previous block's epilogue); aware_tune(2, 0) selects the
+    readout_x3_kernel (fed by split-K partials from the previous block's epilogue); aware_embed_config.readout = 1 selects the
     split-K GEMM + tail kernel + data-gradient GEMM that ragged batches use.  Same loss, prediction, gradient,
     best-loss bookkeeping and step counter from both."""
     B = 5
@@ -361,18 +357,16 @@ def test_fused_readout_vs_three_kernel_path(rt, plan, det, O, n):
     wm = np.stack([O.bits_to_bipolar(p[1]) for p in pairs]).astype(np.float32)
     batch = rt.Batch([n] * B)
     res = []
-    try:
-        for fused in (1, 0):
-            rt.tune(2, fused)
-            sess = rt.EmbedSession(plan, det, batch, use_graph=False)
-            sess.begin(batch.pack([p[0] for p in pairs]), torch.from_numpy(wm).cuda())
-            g = sess.gradient().cpu().double()
-            l0, p0 = sess.loss.cpu().numpy().copy(), sess.pred.cpu().numpy().copy()
-            sess.iterate(3)
-            torch.cuda.synchronize()
-            res.append((g, l0, p0, sess.loss.cpu().numpy().copy(), sess.best_loss.cpu().numpy().copy(), int(sess.step.cpu()[0])))
-    finally:
-        rt.tune(2, 1)
+    for fused in (True, False):
+        sess = rt.EmbedSession(plan, det, batch, use_graph=False, fused_readout=fused)
+        sess.begin(batch.pack([p[0] for p in pairs]), torch.from_numpy(wm).cuda())
+        g = sess.gradient().cpu().double()
+        l0, p0 = sess.loss.cpu().numpy().copy(), sess.pred.cpu().numpy().copy()
+        # a gradient-only call leaves the best-loss bookkeeping untouched (still +inf from begin())
+        assert bool(torch.isinf(sess.best_loss).all())
+        sess.iterate(3)
+        torch.cuda.synchronize()
+        res.append((g, l0, p0, sess.loss.cpu().numpy().copy(), sess.best_loss.cpu().numpy().copy(), int(sess.step.cpu()[0])))
     (g1, l1, p1, l1b, b1, s1), (g0, l0, p0, l0b, b0, s0) = res
     assert np.max(np.abs(l1 - l0)) < 2e-6 and np.max(np.abs(p1 - p0)) < 2e-6
     emb = O.Embedder()
@@ -391,7 +385,7 @@ def test_fused_readout_vs_three_kernel_path(rt, plan, det, O, n):
 def test_fused_path_on_another_detector_geometry(rt, plan, O):
     """A detector with other layer widths (128 -> 256 -> 512 -> 32, 16 bits): two column slabs in the first block,
     four split-K slabs and two read-out workgroups per clip, two 16-column tiles in the last block.  The fused
-    bf16x3 path must agree with the f32-MFMA three-kernel path (aware_tune(1, 0) + aware_tune(2, 0))."""
+    bf16x3 path must agree with the f32-MFMA three-kernel path (aware_embed_config conv_pipe = 1, readout = 1)."""
     g = torch.Generator().manual_seed(11)
     ch = [128, 256, 512, 32]
     ws = [((torch.rand(ch[i + 1], ch[i], generator=g) * 2 - 1) * (6.0 / (ch[i] + ch[i + 1])) ** 0.5).numpy() for i in range(3)]
@@ -402,17 +396,11 @@ def test_fused_path_on_another_detector_geometry(rt, plan, O):
     wm = (torch.randint(0, 2, (B, 16), generator=g).float() * 2 - 1)
     batch = rt.Batch([n] * B)
     res = []
-    try:
-        for fused in (True, False):
-            rt.tune(1, 4 if fused else 0)
-            rt.tune(2, 1 if fused else 0)
-            sess = rt.EmbedSession(plan, det2, batch, use_graph=False)
-            sess.begin(batch.pack(clips), wm.cuda())
-            grad = sess.gradient().cpu().double()
-            res.append((grad, sess.loss.cpu().numpy().copy(), sess.pred.cpu().numpy().copy()))
-    finally:
-        rt.tune(1, 4)
-        rt.tune(2, 1)
+    for fused in (True, False):
+        sess = rt.EmbedSession(plan, det2, batch, use_graph=False, conv_pipe="bf16x3" if fused else "f32", fused_readout=fused)
+        sess.begin(batch.pack(clips), wm.cuda())
+        grad = sess.gradient().cpu().double()
+        res.append((grad, sess.loss.cpu().numpy().copy(), sess.pred.cpu().numpy().copy()))
     (g1, l1, p1), (g0, l0, p0) = res
     assert p1.shape == (B, 16)
     assert np.max(np.abs(l1 - l0)) < 5e-6 and np.max(np.abs(p1 - p0)) < 5e-6

@@ -10,14 +10,13 @@ iters = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 graph = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 n = 48000
 plan = rt.Plan()
-if len(sys.argv) > 4:
-    plan.lib.aware_tune(1, int(sys.argv[4]))
+pipe = "f32" if len(sys.argv) > 4 and sys.argv[4] == "f32" else "bf16x3"
 det = AWAREDetectorNet().device_weights(plan)
 batch = rt.Batch([n] * B)
 g = torch.Generator(device="cuda").manual_seed(0)
 audio = 0.1 * torch.randn(B * n, device="cuda", generator=g)
 target = (torch.randint(0, 2, (B, 20), device="cuda", generator=g).float() * 2 - 1)
-sess = rt.EmbedSession(plan, det, batch, use_graph=bool(graph))
+sess = rt.EmbedSession(plan, det, batch, use_graph=bool(graph), conv_pipe=pipe, num_iterations=iters + 16)
 sess.begin(audio, target)
 sess.iterate(5)
 torch.cuda.synchronize()
