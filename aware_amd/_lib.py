@@ -100,6 +100,7 @@ SIGNATURES = {
     "aware_waveform_normalize": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "aware_upfirdn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp]),
     "aware_iir": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "aware_decimate_interp": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "aware_segment_cut": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "aware_phase_vocoder": (_i, [_vp, _vp, _vp, _vp, _i, C.c_double, _vp]),
     "aware_snr": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),

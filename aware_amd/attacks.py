@@ -90,7 +90,8 @@ def resample_poly_batch(x: "rt.Ragged", up: int, down: int) -> "rt.Ragged":
 
 @register
 class Resample(Attack):
-    """:256-294.  At sr == target (16 kHz) the reference runs the polyphase 441/160 round trip."""
+    """:256-294.  sr // target_sr > 1: decimate without anti-alias filter + np.interp back (float64, :275-288);
+    otherwise (the harness's sr == target == 16 kHz) the polyphase 441/160 round trip (:290-293)."""
 
     def __init__(self, target_sr=16000):
         self.target_sr = target_sr
@@ -98,7 +99,7 @@ class Resample(Attack):
 
     def apply_batch(self, x, sr):
         if sr // self.target_sr > 1:
-            raise NotImplementedError("decimate + linear-interpolate branch (sr >= 2*target_sr) is not on the HIP path")
+            return rt.decimate_interp(x, sr // self.target_sr)
         return resample_poly_batch(resample_poly_batch(x, 441, 160), 160, 441)
 
 

@@ -239,7 +239,36 @@ __global__ __launch_bounds__(256) void segment_copy_kernel(const float* __restri
     }
 }
 
+// Resample's branch for sr // target_sr = k > 1 (scripts/attacks.py:275-288): keep every k-th sample, then
+// np.interp back onto 0..n-1.  np.interp works in float64: slope = (y[i+1] - y[i]) / (x[i+1] - x[i]),
+// value = slope * (x - x[i]) + y[i] (two roundings, no fused multiply-add), exact sample points return y[i], positions
+// beyond the last kept sample return it (numpy/_core/src/multiarray/compiled_base.c arr_interp).  Output float64.
+__global__ __launch_bounds__(256) void decimate_interp_kernel(const float* __restrict__ in, const int* __restrict__ off,
+                                                               const int* __restrict__ len, double* __restrict__ out, int k) {
+    const int b = blockIdx.y;
+    const int n = len[b];
+    const float* x = in + off[b];
+    double* y = out + off[b];
+    const int last = ((n - 1) / k) * k;                     // position of the last kept sample
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        const int i0 = (j / k) * k;
+        double v;
+        if (j >= last) v = (double)x[last];
+        else if (j == i0) v = (double)x[i0];
+        else {
+            const double y0 = (double)x[i0], y1 = (double)x[i0 + k];
+            const double slope = __ddiv_rn(__dsub_rn(y1, y0), (double)k);
+            v = __dadd_rn(__dmul_rn(slope, (double)(j - i0)), y0);
+        }
+        y[j] = v;
+    }
+}
+
 static inline int gx(int max_len) { int g = (max_len + 1023) / 1024; return g < 1 ? 1 : g; }
+void launch_decimate_interp(const float* in, const int* off, const int* len, double* out, int k, int B, int max_len,
+                            hipStream_t st) {
+    hipLaunchKernelGGL(decimate_interp_kernel, dim3(gx(max_len), B), dim3(256), 0, st, in, off, len, out, k);
+}
 
 void launch_pcm_quantize(const float* in, float* out, const int* off, const int* len, const unsigned long long* pmax,
                          const int* pcount, int pstride, float q, float lo, float hi, int B, int max_len,

@@ -994,6 +994,14 @@ extern "C" int aware_iir(const float* in, const int* off, const int* len, int B,
     return AWARE_OK;
 }
 
+extern "C" int aware_decimate_interp(const float* in, const int* off, const int* len, int B, int max_len, int factor,
+                                     double* out, void* stream) {
+    if (!in || !off || !len || !out || B < 1 || factor < 2) return AWARE_E_BADARG;
+    launch_decimate_interp(in, off, len, out, factor, B, max_len, (hipStream_t)stream);
+    LAUNCHCHK();
+    return AWARE_OK;
+}
+
 extern "C" int aware_segment_cut(const float* in, const int* in_off, float* out, const int* out_off,
                                  const int* out_len, const int* cut_start, const int* cut_len, int zero_fill, int B,
                                  int max_len, void* stream) {

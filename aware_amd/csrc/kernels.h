@@ -133,6 +133,8 @@ void launch_snr(const float* a, const int* a_off, const float* b, const int* b_o
                 hipStream_t st);
 void launch_phase_vocoder(const void* in, const int* fin, void* out, const int* fout, double rate, int B, hipStream_t st);
 void launch_spectral_quantize(void* spec, int nframes, float step_db, float floor_db, hipStream_t st);
+void launch_decimate_interp(const float* in, const int* off, const int* len, double* out, int k, int B, int max_len,
+                            hipStream_t st);
 void launch_segment_copy(const float* in, const int* in_off, float* out, const int* out_off, const int* out_len,
                          const int* cut_start, const int* cut_len, int zero_fill, int B, int max_len, hipStream_t st);
 

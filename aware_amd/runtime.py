@@ -401,6 +401,15 @@ def iir(x: Ragged, b: np.ndarray, a: np.ndarray, zi: np.ndarray | None = None, f
     return out
 
 
+def decimate_interp(x: Ragged, factor: int) -> Ragged:
+    """x[::factor] then np.interp back to the original length (float64 result), per clip."""
+    lib = load_library()
+    out = x.like(torch.float64)
+    check(lib.aware_decimate_interp(_ptr(x.data), _ptr(x.d_off), _ptr(x.d_len), x.B, x.max_len, int(factor), _ptr(out.data),
+                                    _stream()), "aware_decimate_interp")
+    return out
+
+
 def segment_cut(x: Ragged, starts: Sequence[int], cuts: Sequence[int], zero_fill: bool) -> Ragged:
     lib = load_library()
     dev = x.data.device

@@ -178,6 +178,11 @@ int aware_waveform_normalize(const float* in, float* out, const int* off, const 
 int aware_upfirdn(const float* in, const int* in_off, const int* in_len, float* out, const int* out_off,
                   const int* out_len, int B, int max_out, const float* h, int nh, int up, int down,
                   int half_len, void* stream);
+/* Resample.apply's branch for sr // target_sr = factor > 1 (scripts/attacks.py:275-288): keep every factor-th sample
+ * and linearly interpolate back to the original length with np.interp's float64 arithmetic.  out: dev f64 at the
+ * same offsets as `in`. */
+int aware_decimate_interp(const float* in, const int* off, const int* len, int B, int max_len, int factor,
+                          double* out, void* stream);
 /* scipy.signal.lfilter (LowPassFilter / HighPassFilter :400-455) and filtfilt (RandomBandstop
  * :324-356) in f64.  b, a: dev f64 [B][ncoef] (a[0] == 1); zi: dev f64 [B][ncoef-1] (filtfilt only).
  * out is f64 when out_f64 != 0 (the reference returns float64 from lfilter), else f32.

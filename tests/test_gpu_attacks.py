@@ -175,3 +175,69 @@ def test_pitch_shift_extension(A):
         assert np.max(np.abs(got - ref)) < 5e-5 * max(1.0, np.max(np.abs(ref)))
         assert abs(len(got) - len(a)) < 0.02 * len(a) + 1024          # back to (about) the original duration
     assert A.PitchShift(5).name == "ps_5" and A.TimeStretch(1.1).name == "ts_1.1"
+
+
+# ---- round-2 fixtures (tests/golden/attacks_r2.npz, tools/make_golden_r2.py) ------------------------------------
+@pytest.fixture(scope="module")
+def gold2():
+    return np.load(os.path.join(GOLDEN, "attacks_r2.npz"))
+
+
+def test_resample_decimate_branch_bit_exact(A, gold, gold2):
+    """Resample with sr // target_sr > 1 (scripts/attacks.py:275-288): x[::k] + np.interp, float64 like numpy --
+    bit-exact (the kernel keeps np.interp's two roundings; no fused multiply-add)."""
+    src = gold["src"]
+    o2 = A.Resample(8000).apply(src, 16000)                  # factor 2
+    assert o2.dtype == np.float64 and o2.shape[0] == int(gold2["1s/decimate2/len"])
+    np.testing.assert_array_equal(o2, gold2["1s/decimate2/out"])
+    o3 = A.Resample(16000).apply(src, 48000)                 # factor 3
+    np.testing.assert_array_equal(o3, gold2["1s/decimate3/out"])
+    # ragged batch, lengths that are / are not multiples of the factor; against the oracle's np.interp restatement
+    from oracle import aware_oracle as O
+    from aware_amd import runtime as rt
+    clips = [src[:1000], src[:1001], src[:1002], src[:7]]
+    out = A.Resample(16000).apply_batch(rt.Ragged.from_list(clips), 48000).to_list()
+    for c, o in zip(clips, out):
+        np.testing.assert_array_equal(o, O.resample_attack(c, 48000, 16000))
+
+
+def test_delete_015_and_3s_attack_fixture(A, gold, gold2):
+    """DeleteSamples(0.15) on the 1 s clip, then every in-scope attack on the reference's own 3 s watermarked clip:
+    index / integer attacks bit-exact, filters to 1e-6, resampler to 3e-6, and the detector's raw outputs on the attacked
+    audio against the reference's (1e-4)."""
+    import random
+    np.random.seed(1234)
+    np.testing.assert_array_equal(A.DeleteSamples(0.15).apply(gold["src"], 16000), gold2["1s/delete_0.15/out"])
+    src = gold2["3s/src"]
+    from aware_amd.utils.models import load
+    emb, det = load()
+    outs = {}
+    exact = {"pcm_8": lambda: A.PCMBitDepthConversion(8), "pcm_16": lambda: A.PCMBitDepthConversion(16),
+             "delete_0.1": lambda: A.DeleteSamples(0.1), "delete_0.15": lambda: A.DeleteSamples(0.15),
+             "delete_0.2": lambda: A.DeleteSamples(0.2), "cropout_0.1": lambda: A.Cropout(0.1),
+             "suppress_0.1": lambda: A.SampleSupression(0.1), "suppress_0.25": lambda: A.SampleSupression(0.25)}
+    for k, mk in exact.items():
+        np.random.seed(1234)
+        random.seed(1234)
+        o = mk().apply(src, 16000)
+        assert o.shape[0] == int(gold2[f"3s/{k}/len"])
+        np.testing.assert_array_equal(o[::8], gold2[f"3s/{k}/out_sample"])
+        assert float(np.sum(o, dtype=np.float64)) == float(gold2[f"3s/{k}/sum"])
+        outs[k] = o
+    tol = {"resample": 3e-6, "low_pass": 1e-6, "high_pass": 1e-6, "bandstop": 1e-6}
+    mkf = {"resample": lambda: A.Resample(), "low_pass": lambda: A.LowPassFilter(), "high_pass": lambda: A.HighPassFilter(),
+           "bandstop": lambda: A.RandomBandstop()}
+    for k, mk in mkf.items():
+        random.seed(1234)
+        o = mk().apply(src, 16000)
+        np.testing.assert_allclose(o[::8], gold2[f"3s/{k}/out_sample"], atol=tol[k])
+        assert abs(float(np.sum(o, dtype=np.float64)) - float(gold2[f"3s/{k}/sum"])) < 48000 * tol[k]
+        outs[k] = np.asarray(o, dtype=np.float32)
+    keys = sorted(outs)
+    vals = det.detect_batch([outs[k] for k in keys], 16000).cpu().numpy()
+    bits = gold2["3s/bits"]
+    for k, v in zip(keys, vals):
+        np.testing.assert_allclose(v, gold2[f"3s/{k}/det_raw"], atol=1e-4)
+        # BER after the attack equals the reference's (0 errors on this clip for every attack)
+        np.testing.assert_array_equal((v > 0).astype(np.int32), (gold2[f"3s/{k}/det_raw"] > 0).astype(np.int32))
+        assert int(((v > 0).astype(np.int32) != bits).sum()) == 0

@@ -277,7 +277,7 @@ def test_embed_short_trajectory(rt, plan, det, O):
         emb.embed(c[None], wm[i][None], record=lambda it, l, p, g: ref.append(float(l[0])))
         ref = np.asarray(ref)
         assert abs(mine[0, i] - ref[0]) < 2e-5
-        assert np.max(np.abs(mine[:, i] - ref)) < 2e-2, (mine[:, i], ref)
+        assert np.max(np.abs(mine[:, i] - ref)) < 3 * 1.2e-3, (mine[:, i], ref)       # 3x the measured 20-step drift (DRIFT below)
     assert int(sess.step.cpu()[0]) == 20
 
 
@@ -296,7 +296,7 @@ def test_embed_full_1s_bits_exact(rt, plan, det, O):
     out = sess.finish(rescale)
     torch.cuda.synchronize()
     best = float(sess.best_loss.cpu()[0])
-    assert abs(best - float(e["losses"].min())) < 2e-2, best
+    assert abs(best - float(e["losses"].min())) < 3 * 1.6e-3, best            # 3x measured (profiles/r02_drift.json)
     out_c = out.cpu().numpy()
     assert out_c.shape[0] == int(e["out_len"])
     # normalised to unit peak, then rescaled by the signed input maximum (service/embed.py:69,73)
@@ -407,3 +407,129 @@ def test_fused_path_on_another_detector_geometry(rt, plan, O):
     rel = ((g1 - g0).norm() / g0.norm()).item()
     print("relative L2 difference of the gradients, fused bf16x3 vs f32 three-kernel path:", rel)
     assert rel < 1e-3, rel            # loose: a random detector has no guarantee against LeakyReLU kinks
+
+
+# ---------------------------------------------------------------------------------------------------------
+# round 2: the tolerance box, the 3 s golden trajectory and the 44.1 kHz golden on the HIP path
+# (tolerances = 3x the drift measured on MI355X by tools/measure_drift.py, recorded in profiles/r02_drift.json)
+# ---------------------------------------------------------------------------------------------------------
+# Measured on MI355X against the reference's recorded run (profiles/r02_drift.json; worst of the 1 s and 3 s golden
+# clips; the f32-MFMA pipe drifts by the same amounts, 5.8e-3 / 3.7e-3 max): |loss - reference loss| is 0 at step 0,
+# <= 1.2e-3 over the first 20 steps (the 3 s clip has a LeakyReLU argument 2e-7 from its kink), <= 5.2e-3 at any of
+# the 400 steps; best loss 1.5e-3; raw detector outputs of the watermarked clip 1.6e-2; waveform rel-L2 6.6e-2.
+# Two CPU runs of the reference itself differ by ~1e-3 at step 400.  Tolerances below = 3x measured.
+DRIFT = {"step0": 7e-7, "first20": 1.2e-3, "any": 5.2e-3, "best": 1.6e-3, "out_rel_l2": 0.05, "raw": 1.6e-2}
+
+
+@pytest.mark.parametrize("lengths,seeds", [([16000], [1]), ([48000, 16000, 23456], [0, 1, 2])])
+def test_bounds_vs_oracle_and_golden(rt, plan, det, O, lengths, seeds):
+    """The imperceptibility box [max(0, c - d), c + d], d = c * 10^(-6/20) (multibit_embedder.py:157-160): sess.bounds
+    against the oracle's bounds() of the oracle's own analysis (<= 2 ulp of the magnitude, which itself is pinned to
+    1e-5 relative) and the reference's recorded extremes."""
+    pairs = [make_clip(s, n) for s, n in zip(seeds, lengths)]
+    batch = rt.Batch(lengths)
+    sess = rt.EmbedSession(plan, det, batch, use_graph=False)
+    wm = np.stack([O.bits_to_bipolar(p[1]) for p in pairs]).astype(np.float32)
+    sess.begin(batch.pack([p[0] for p in pairs]), torch.from_numpy(wm).cuda())
+    torch.cuda.synchronize()
+    lo, hi = sess.bounds
+    c0 = sess.coef.cpu()
+    lo, hi = lo.cpu(), hi.cpu()
+    emb = O.Embedder()
+    for i, (a, _) in enumerate(pairs):
+        sl = slice(batch.frame_offsets[i], batch.frame_offsets[i + 1])
+        mag0, _ = emb.analyse(torch.from_numpy(a)[None])
+        cref = mag0[0, emb.band]                                   # [225, T]
+        lref, href = emb.bounds(cref)
+        mine_c, mine_lo, mine_hi = c0[sl, :225].T, lo[sl, :225].T, hi[sl, :225].T
+        scale = float(cref.max())
+        assert float((mine_c - cref).abs().max()) < 1e-5 * scale
+        # the box is a function of c alone: compare with the oracle's formula applied to the HIP path's own c
+        l2, h2 = emb.bounds(mine_c)
+        ulp = np.spacing(np.float32(scale))
+        assert float((mine_lo - l2).abs().max()) <= 2 * ulp and float((mine_hi - h2).abs().max()) <= 2 * ulp
+        assert float((mine_lo - lref).abs().max()) < 2e-5 * scale and float((mine_hi - href).abs().max()) < 2e-5 * scale
+        assert bool((mine_lo >= 0).all())
+        # columns 225..255 of a row are padding: zero box
+        assert float(lo[sl, 225:].abs().max()) == 0.0 and float(hi[sl, 225:].abs().max()) == 0.0
+    if seeds[0] == 1:
+        e = np.load(os.path.join(GOLDEN, "embed_1s.npz"))
+        T = batch.frames[0]
+        assert abs(float(hi[:T, :225].max()) - float(e["bound_hi_max"])) < 2e-5 * float(e["bound_hi_max"])
+        assert abs(float(lo[:T, :225].min()) - float(e["bound_lo_min"])) < 1e-6
+        assert abs(float(c0[:T, :225].double().sum()) - float(e["coeffs0_sum"])) < 1e-5 * abs(float(e["coeffs0_sum"]))
+    else:
+        e = np.load(os.path.join(GOLDEN, "embed_3s.npz"))
+        T = batch.frames[0]
+        assert abs(float(hi[:T, :225].max()) - float(e["bound_hi_max"])) < 2e-5 * float(e["bound_hi_max"])
+        assert abs(float(lo[:T, :225].min()) - float(e["bound_lo_min"])) < 1e-6
+
+
+@pytest.mark.parametrize("tag,seed,n", [("1s", 1, 16000), ("3s", 0, 48000)])
+def test_embed_golden_trajectory_400_steps(rt, plan, det, O, tag, seed, n):
+    """The reference's own 400-step loss trajectory (embed_1s.npz / embed_3s.npz `losses`) on the HIP path, step by
+    step: step 0 to f32 rounding, the first 20 steps, every step, the best loss, the final bits (exact), the detector's
+    raw outputs on the watermarked audio and the distance to the reference's watermarked waveform."""
+    e = np.load(os.path.join(GOLDEN, f"embed_{tag}.npz"))
+    audio, bits = make_clip(seed, n)
+    wm = O.bits_to_bipolar(bits).astype(np.float32)[None]
+    batch = rt.Batch([n])
+    sess = rt.EmbedSession(plan, det, batch, use_graph=True)
+    sess.begin(batch.pack([audio]), torch.from_numpy(wm).cuda())
+    mine = []
+    for _ in range(400):
+        sess.iterate(1)
+        mine.append(float(sess.loss.cpu()[0]))
+    with pytest.raises(ValueError):
+        sess.iterate(1)                                  # a 401st step is refused (the NAdam table has 400)
+    mine = np.asarray(mine)
+    ref = e["losses"]
+    d = np.abs(mine - ref)
+    print(f"{tag}: |loss - reference| step0 {d[0]:.2e} first20 {d[:20].max():.2e} step200 {d[200]:.2e} step399 {d[399]:.2e} "
+          f"max {d.max():.2e} (step {d.argmax()})")
+    assert d[0] < 3 * DRIFT["step0"]
+    assert d[:20].max() < 3 * DRIFT["first20"]
+    assert d.max() < 3 * DRIFT["any"]
+    for s in (0, 200, 399):
+        assert abs(mine[s] - ref[s]) < 3 * DRIFT["any"]
+    best = float(sess.best_loss.cpu()[0])
+    assert abs(best - float(ref.min())) < 3 * DRIFT["best"]
+    out = sess.finish(torch.tensor([float(np.max(audio))], device="cuda"))
+    out_c = out.cpu().numpy()
+    assert out_c.shape[0] == int(e["out_len"])
+    step = int(e["out_step"])
+    rel = np.linalg.norm(out_c[::step] - e["out_sample"]) / np.linalg.norm(e["out_sample"])
+    print(f"{tag}: relative L2 distance to the reference's watermarked audio {rel:.3e}")
+    assert rel < 3 * DRIFT["out_rel_l2"]
+    vals = rt.detect(plan, det, rt.Batch([out_c.shape[0]]), out).cpu().numpy()[0]
+    np.testing.assert_array_equal(O.decode_bits(vals), e["det_bits"])
+    np.testing.assert_array_equal(O.decode_bits(vals), bits)
+    print(f"{tag}: max |raw - reference raw_marked| {np.max(np.abs(vals - e['raw_marked'])):.2e}")
+    assert np.max(np.abs(vals - e["raw_marked"])) < 3 * DRIFT["raw"]
+
+
+def test_config1_44k_golden_on_gpu(rt, plan, det, O):
+    """BASELINE config 1 on the HIP path: 44.1 kHz clip -> polyphase 160/441 -> embed -> detect, against the
+    reference's recorded output (config1_44k.npz): front end to 3e-7, bits exact, raw detector outputs and waveform
+    within the measured 400-step drift."""
+    from aware_amd.attacks import resample_poly_batch
+    c = np.load(os.path.join(GOLDEN, "config1_44k.npz"))
+    rng = np.random.default_rng(0)
+    a441 = (0.1 * rng.standard_normal(132300)).astype(np.float32)
+    bits = rng.integers(0, 2, 20).astype(np.int32)
+    a16 = resample_poly_batch(rt.Ragged.from_list([a441]), 16000, 44100).to_list()[0]
+    np.testing.assert_allclose(a16[::16], c["a16_sample"], atol=3e-7)
+    wm = O.bits_to_bipolar(bits).astype(np.float32)[None]
+    batch = rt.Batch([48000])
+    sess = rt.EmbedSession(plan, det, batch, use_graph=True)
+    sess.begin(batch.pack([a16]), torch.from_numpy(wm).cuda())
+    sess.iterate(400)
+    out = sess.finish(torch.tensor([float(np.max(a16))], device="cuda"))
+    out_c = out.cpu().numpy()
+    assert out_c.shape[0] == int(c["out_len"])
+    vals = rt.detect(plan, det, rt.Batch([out_c.shape[0]]), out).cpu().numpy()[0]
+    np.testing.assert_array_equal(O.decode_bits(vals), c["det_bits"])
+    print("config1: max |raw - reference|", np.max(np.abs(vals - c["raw_marked"])))
+    assert np.max(np.abs(vals - c["raw_marked"])) < 3 * DRIFT["raw"]
+    rel = np.linalg.norm(out_c[::16] - c["out_sample"]) / np.linalg.norm(c["out_sample"])
+    assert rel < 3 * DRIFT["out_rel_l2"]

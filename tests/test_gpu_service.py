@@ -231,8 +231,8 @@ def test_edge_cases(models):
         emb.num_iterations = emb2_iters
 
 
-def test_full_size_config1_properties(models):
-    """BASELINE config 1 at full size (64 x 3 s clips from 44.1 kHz): size-independent properties --
+def test_full_size_config2_properties(models):
+    """BASELINE config 2 at full size (64 x 3 s clips from 44.1 kHz): size-independent properties --
     every clip decodes exactly (BER 0), the best loss improved on the first iteration's for every
     clip, the watermark stays inside the +-6 dB box, outputs are unit-peak times the input maximum,
     and a second run is bit-identical (no atomics anywhere on the path)."""
@@ -260,8 +260,8 @@ def test_full_size_config1_properties(models):
     assert float(r1.values.abs().min()) > 0.15
 
 
-def test_full_size_config2_properties(models):
-    """BASELINE config 2 at full size (256 x 3 s clips from 44.1 kHz, attack stack resample 16k<->44.1k + low-pass +
+def test_full_size_config3_properties(models):
+    """BASELINE config 3 at full size (256 x 3 s clips from 44.1 kHz, attack stack resample 16k<->44.1k + low-pass +
     Gaussian noise 20 dB + PCM 16): the clean read-out of every clip is exact, the attacked read-out stays far from
     chance, SNR of the watermark is finite and in the range the +-6 dB box allows, and a second run is bit-identical
     up to the detected bits (the noise attack is keyed per clip, so it repeats too)."""
@@ -279,6 +279,49 @@ def test_full_size_config2_properties(models):
     r2 = pipe.run(audio, bits, input_rate=44100)
     assert torch.equal(r1.watermarked.data, r2.watermarked.data)
     assert torch.equal(r1.bits, r2.bits)
+
+
+def test_full_size_config5_properties(models):
+    """BASELINE config 5 at one GPU's share (128 clips of seeded 1..10 s from 44.1 kHz, 400 iterations, a seeded chain
+    of 1..3 attacks per clip out of {pcm16, resample, lowpass, bandstop, cut 10 %, gaussian 20 dB}, bench.py's own
+    plan): size-independent properties -- every clip's clean read-out is exact, the attacked read-out stays far from
+    chance overall and exact for the chains made of benign attacks only, every clip's optimiser ran 400 steps inside
+    its box, output lengths follow 256*(T-1), and the embed is bit-identical on a second run (ragged path: no atomics)."""
+    import random
+    import bench
+    from aware_amd.pipeline import WatermarkPipeline, synthetic_ragged_clips
+    emb, det = models
+    secs, chains = bench.config5_plan(128, 1)
+    assert min(secs) == 1 and max(secs) == 10 and len(set(map(tuple, chains))) > 20
+    order = sorted(range(128), key=lambda i: (-secs[i], i))
+    secs, chains = [secs[i] for i in order], [chains[i] for i in order]
+    audio, bits = synthetic_ragged_clips(secs, 44100, seeds=order)
+    pipe = WatermarkPipeline(emb, det, [], 16000)
+    random.seed(11)
+    np.random.seed(11)
+    r1 = pipe.run(audio, bits, input_rate=44100, chains_by_kind=(chains, bench.make_attack_of_kind))
+    assert abs(r1.seconds - float(sum(secs))) < 1e-6
+    assert int(r1.clean_bit_errors) == 0
+    wrong = (r1.bits != bits).sum(dim=1).cpu().numpy()
+    assert wrong.sum() <= 0.05 * bits.numel(), wrong
+    benign = [i for i, c in enumerate(chains) if set(c) <= {"pcm", "resample", "lowpass"}]
+    assert len(benign) >= 10 and int(wrong[benign].sum()) == 0
+    key = next(k for k in pipe._sessions if not isinstance(k[0], str))
+    batch, sess = pipe._sessions[key]
+    assert batch.B == 128 and max(batch.frames) == 626 and min(batch.frames) == 63
+    assert r1.watermarked.lengths == [256 * (t - 1) for t in batch.frames]
+    assert int(sess.step.cpu()[0]) == 400
+    best = sess.best_loss.cpu().numpy()
+    assert np.all(np.isfinite(best)) and np.all(best < 0.7)
+    lo, hi = sess.bounds
+    bc = sess.best_coef
+    assert bool(((bc >= lo) & (bc <= hi)).all())
+    w1 = r1.watermarked.data.clone()
+    random.seed(11)
+    np.random.seed(11)
+    r2 = pipe.run(audio, bits, input_rate=44100, chains_by_kind=(chains, bench.make_attack_of_kind))
+    assert torch.equal(w1, r2.watermarked.data)
+    assert torch.equal(r1.bits, r2.bits)                      # same host draws -> same attacked audio -> same bits
 
 
 def test_degenerate_inputs_stay_finite(models):

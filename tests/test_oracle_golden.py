@@ -164,6 +164,39 @@ def test_attacks_golden():
         np.testing.assert_allclose(raw, a[key + "/det_raw"], atol=5e-5)
 
 
+def test_attacks_golden_r2():
+    """Round-2 fixtures (tools/make_golden_r2.py): the decimate + np.interp branch of Resample, DeleteSamples(0.15),
+    and every in-scope attack on the reference's 3 s watermarked clip."""
+    a, r = g("attacks_1s.npz"), g("attacks_r2.npz")
+    src = a["src"]
+    o2 = O.resample_attack(src, 16000, 8000)
+    assert o2.dtype == np.float64
+    np.testing.assert_array_equal(o2, r["1s/decimate2/out"])
+    np.testing.assert_array_equal(O.resample_attack(src, 48000, 16000), r["1s/decimate3/out"])
+    np.testing.assert_array_equal(O.delete_samples_attack(src, 0.15, start=int(r["1s/delete_0.15/start"])), r["1s/delete_0.15/out"])
+    s3 = r["3s/src"]
+    emb = O.Embedder()
+    outs = {"pcm_8": O.pcm_bit_depth(s3, 8), "pcm_16": O.pcm_bit_depth(s3, 16), "cropout_0.1": O.cropout_attack(s3, 0.1)}
+    for p in ("0.1", "0.15", "0.2"):
+        outs[f"delete_{p}"] = O.delete_samples_attack(s3, float(p), start=int(r[f"3s/delete_{p}/start"]))
+    for p in ("0.1", "0.25"):
+        outs[f"suppress_{p}"] = O.sample_suppression_attack(s3, float(p), start=int(r[f"3s/suppress_{p}/start"]))
+    for k, o in outs.items():
+        np.testing.assert_array_equal(np.asarray(o)[::8], r[f"3s/{k}/out_sample"])
+        assert float(np.sum(o, dtype=np.float64)) == float(r[f"3s/{k}/sum"])
+    flt = {"resample": (O.resample_attack(s3), 3e-6), "low_pass": (O.lowpass_attack(s3), 1e-6),
+           "high_pass": (O.highpass_attack(s3), 1e-6),
+           "bandstop": (O.bandstop_attack(s3, f_low=float(r["3s/bandstop/f_low"])), 1e-6)}
+    for k, (o, tol) in flt.items():
+        np.testing.assert_allclose(np.asarray(o)[::8], r[f"3s/{k}/out_sample"], atol=tol)
+        outs[k] = o
+    np.testing.assert_allclose(emb.detect_raw(s3[None])[0].numpy(), r["3s/det_raw_clean"], atol=5e-5)
+    for k in ("pcm_8", "resample", "low_pass", "delete_0.15", "suppress_0.25", "bandstop"):
+        raw = emb.detect_raw(np.asarray(outs[k], dtype=np.float32)[None])[0].numpy()
+        np.testing.assert_allclose(raw, r[f"3s/{k}/det_raw"], atol=5e-5)
+        assert int(((raw > 0).astype(np.int32) != r["3s/bits"]).sum()) == 0
+
+
 def test_filter_design_matches_scipy():
     sig = pytest.importorskip("scipy.signal")
     for args in ((6, 0.5, "low"), (4, 0.0625, "highpass"), (4, [0.1, 0.125], "bandstop")):
