@@ -13,7 +13,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AWARE_HIP_LIB") or os.path.join(_HERE, "libaware_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["capi.hip", "dsp_kernels.hip", "detector_kernels.hip", "gemm_x3.hip", "attack_kernels.hip"]
+SOURCES = ["capi.hip", "dsp_kernels.hip", "dsp_stream.hip", "detector_kernels.hip", "gemm_x3.hip", "attack_kernels.hip"]
 
 AWARE_OK = 0
 ERRORS = {-1: "bad argument", -2: "unsupported configuration", -3: "HIP runtime error", -4: "workspace too small"}
@@ -28,7 +28,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     without a GPU).  Each source is compiled to an object under csrc/build/ (only those older than
     their inputs, in parallel), then linked."""
     from concurrent.futures import ThreadPoolExecutor
-    hdrs = [os.path.join(CSRC, h) for h in ("common.hpp", "fft512.hpp", "kernels.h")] + [
+    hdrs = [os.path.join(CSRC, h) for h in ("common.hpp", "fft512.hpp", "kernels.h", "dsp_args.hpp")] + [
         os.path.join(_HERE, "..", "include", "aware_hip.h")]
     hdr_t = max(os.path.getmtime(h) for h in hdrs)
     bdir = os.path.join(CSRC, "build")
@@ -49,7 +49,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
 
-    with ThreadPoolExecutor(max_workers=min(5, max(1, len(jobs)))) as ex:
+    with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
     run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs)
     return LIB_PATH
@@ -58,7 +58,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
 class EmbedConfig(C.Structure):
     _fields_ = [("num_iterations", C.c_int), ("tolerance_db", C.c_float), ("loss", C.c_int),
                 ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
-                ("momentum_decay", C.c_float), ("use_graph", C.c_int), ("conv_pipe", C.c_int), ("readout", C.c_int)]
+                ("momentum_decay", C.c_float), ("use_graph", C.c_int), ("conv_pipe", C.c_int), ("readout", C.c_int),
+                ("dsp_path", C.c_int)]
 
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t

@@ -62,6 +62,7 @@ struct aware_batch {
     std::vector<int> n, in_off, T, frame_off, pool_off, out_off, out_len, pc_in, pc_syn;
     int NF = 0, NP = 0, NS = 0, max_frames = 0, max_len = 0, pstride = 0;
     int uniform_tp = 0;   // pooled frames per clip when all clips agree (else 0)
+    int synth_run = kSynthBlocks;   // hop blocks per synthesis run: 16, or 8 / 4 when 16 would leave the chip short of waves
     // device tables (one allocation)
     int* d_mem = nullptr;
     int *d_frame_off = nullptr, *d_pool_off = nullptr, *d_in_off = nullptr, *d_in_len = nullptr, *d_out_off = nullptr,
@@ -166,6 +167,15 @@ extern "C" int aware_batch_create(aware_batch** out, int B, const int* n_samples
     b->pc_in.resize(B);
     b->pc_syn.resize(B);
     int acc = 0, max_pc = 1;
+    // run length of the synthesis kernels (one wave of the streaming kernels per run): the longest of 16 / 8 / 4 hop
+    // blocks that still gives ~12 waves per CU; a run of r blocks transforms r + 3 frames, so short runs cost more
+    // arithmetic and are only worth it while the chip would otherwise idle
+    for (int rb : {16, 8, 4}) {
+        long runs = 0;
+        for (int i = 0; i < B; ++i) runs += (n_samples[i] / kHop + rb - 1) / rb;
+        b->synth_run = rb;
+        if (runs >= 3072) break;
+    }
     b->frame_off[0] = 0;
     b->pool_off[0] = 0;
     for (int i = 0; i < B; ++i) {
@@ -181,7 +191,7 @@ extern "C" int aware_batch_create(aware_batch** out, int B, const int* n_samples
         b->out_off[i] = kHop * (b->frame_off[i] - i);
         b->out_len[i] = kHop * (T - 1);
         b->pc_in[i] = (n + 4095) / 4096;
-        int nseg = (T - 1 + kSynthBlocks - 1) / kSynthBlocks;
+        int nseg = (T - 1 + b->synth_run - 1) / b->synth_run;
         if (nseg < 1) nseg = 1;
         b->pc_syn[i] = nseg;
         if (T > b->max_frames) b->max_frames = T;
@@ -236,6 +246,18 @@ extern "C" size_t aware_batch_scratch_bytes(const aware_batch* b) {
     return b ? (size_t)b->B * b->pstride * sizeof(unsigned long long) + 256 : 0;
 }
 
+// The DSP kernels exist in two forms: streaming wave kernels (dsp_stream.hip; default wherever the band lies inside bins
+// 1..256) and workgroup-staged kernels (dsp_kernels.hip; any band, full-spectrum input/output, and the form the
+// streaming kernels are tested against).  dsp_path: 0 = streaming where supported, 1 = staged.
+static void run_analysis(AnalysisLaunch& L, int dsp_path, hipStream_t st) {
+    if (dsp_path == 0 && !L.full && stream_supported(L.plan)) { L.stream = 1; launch_analysis_stream(L, st); }
+    else launch_analysis(L, st);
+}
+static void run_synth(SynthLaunch& S, int dsp_path, hipStream_t st) {
+    if (dsp_path == 0 && !S.full && stream_supported(S.plan)) { S.stream = 1; launch_synth_stream(S, st); }
+    else launch_synth(S, st);
+}
+
 // ---------------------------------------------------------------------------------------------
 // workspace carving
 struct Carver {
@@ -286,7 +308,7 @@ extern "C" int aware_stft_band(const aware_plan* plan, const aware_batch* b, con
     L.sig = audio; L.sig_off = b->d_in_off; L.sig_len = b->d_in_len;
     L.pmax = normalize ? pmax : nullptr; L.pcount = b->d_pc_in; L.pstride = b->pstride;
     L.mag = mag; L.unit = phasor; L.unit_default = 1.f;
-    launch_analysis(L, st);
+    run_analysis(L, 0, st);
     LAUNCHCHK();
     return AWARE_OK;
 }
@@ -297,7 +319,7 @@ extern "C" int aware_istft(const aware_plan* plan, const aware_batch* b, const v
     hipStream_t st = (hipStream_t)stream;
     unsigned long long* pmax = (unsigned long long*)scratch;
     SynthLaunch S;
-    S.plan = plan->dev; S.frame_off = b->d_frame_off; S.B = b->B; S.max_frames = b->max_frames;
+    S.plan = plan->dev; S.frame_off = b->d_frame_off; S.B = b->B; S.max_frames = b->max_frames; S.run_blocks = b->synth_run;
     S.full = spec; S.out = out; S.pmax = normalize ? pmax : nullptr; S.pstride = b->pstride;
     launch_synth(S, st);
     LAUNCHCHK();
@@ -575,6 +597,7 @@ struct aware_embed {
     cf *P, *U;
     // signals [NS]
     float *yraw, *oob, *gy;
+    float* gpad;          // [B][2][512] reflect-pad parts of the synthesis adjoint (streaming DSP kernels)
     // gradient ping-pong [NP][maxc]
     float *d1, *d2;
     // scalars
@@ -595,6 +618,7 @@ static size_t embed_bytes(const aware_batch* b, const aware_detector* d, int ite
     bytes += (size_t)b->NF * kFS * sizeof(float) * 8;
     bytes += (size_t)b->NF * kFS * sizeof(cf) * 2;
     bytes += (size_t)b->NS * sizeof(float) * 3;
+    bytes += (size_t)b->B * 1024 * sizeof(float);
     bytes += (size_t)b->NP * d->maxc * sizeof(float) * 2;
     bytes += (size_t)b->B * (3 * d->nbits + 8) * sizeof(float);
     bytes += (size_t)(iters + 1) * sizeof(float4);
@@ -612,6 +636,7 @@ extern "C" int aware_embed_create(aware_embed** out, const aware_plan* plan, con
     if (!out || !plan || !det || !b || !cfg || !workspace) return AWARE_E_BADARG;
     if (cfg->num_iterations < 1 || cfg->num_iterations > 4096 || cfg->loss < 0 || cfg->loss > 5) return AWARE_E_BADARG;
     if (cfg->conv_pipe < 0 || cfg->conv_pipe > 1 || cfg->readout < 0 || cfg->readout > 1) return AWARE_E_BADARG;
+    if (cfg->dsp_path < 0 || cfg->dsp_path > 1) return AWARE_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     aware_embed* e = new aware_embed();
     e->plan = plan; e->det = det; e->b = b; e->cfg = *cfg;
@@ -623,6 +648,7 @@ extern "C" int aware_embed_create(aware_embed** out, const aware_plan* plan, con
     e->mag = c.take<float>(nsp); e->gmag = c.take<float>(nsp);
     e->P = c.take<cf>(nsp); e->U = c.take<cf>(nsp);
     e->yraw = c.take<float>(b->NS); e->oob = c.take<float>(b->NS); e->gy = c.take<float>(b->NS);
+    e->gpad = c.take<float>((size_t)b->B * 1024);
     e->d1 = c.take<float>((size_t)b->NP * det->maxc); e->d2 = c.take<float>((size_t)b->NP * det->maxc);
     e->loss = c.take<float>(b->B); e->best_loss = c.take<float>(b->B);
     e->target = c.take<float>((size_t)b->B * det->nbits);
@@ -632,6 +658,10 @@ extern "C" int aware_embed_create(aware_embed** out, const aware_plan* plan, con
     e->pmaxY = c.take<unsigned long long>((size_t)b->B * b->pstride);
     e->pdot = c.take<double>((size_t)b->B * b->pstride);
     if (!c.ok) { delete e; return AWARE_E_WORKSPACE; }
+    // columns nband..255 of every spectral row are padding: zeroed once here, never written by the loop kernels
+    HIPCHK(hipMemsetAsync(e->mag, 0, nsp * sizeof(float), st));
+    HIPCHK(hipMemsetAsync(e->U, 0, nsp * sizeof(cf), st));
+    HIPCHK(hipMemsetAsync(e->gpad, 0, (size_t)b->B * 1024 * sizeof(float), st));
     // torch.optim.NAdam's per-step scalars (torch/optim/nadam.py _single_tensor_nadam):
     // mu_product lives in a float32 tensor and is read back with .item()
     std::vector<float4> sc(cfg->num_iterations + 1);
@@ -711,13 +741,13 @@ extern "C" int aware_embed_begin(aware_embed* e, const float* audio, const float
     L.sig = audio; L.sig_off = b->d_in_off; L.sig_len = b->d_in_len;
     L.pmax = e->pmaxA; L.pcount = b->d_pc_in; L.pstride = b->pstride;
     L.mag = e->mag; L.unit = e->P; L.unit_default = 1.f;
-    launch_analysis(L, st);
+    run_analysis(L, e->cfg.dsp_path, st);
     LAUNCHCHK();
     // constant out-of-band part of every synthesis: x/m - istft(band of the original)
     SynthLaunch S;
-    S.plan = e->plan->dev; S.frame_off = b->d_frame_off; S.B = b->B; S.max_frames = b->max_frames;
+    S.plan = e->plan->dev; S.frame_off = b->d_frame_off; S.B = b->B; S.max_frames = b->max_frames; S.run_blocks = b->synth_run;
     S.amp = e->mag; S.ph = e->P; S.out = e->gy; S.pstride = b->pstride;
-    launch_synth(S, st);
+    run_synth(S, e->cfg.dsp_path, st);
     LAUNCHCHK();
     launch_oob_residual(audio, b->d_in_off, e->pmaxA, b->d_pc_in, b->pstride, e->gy, b->d_frame_off, e->oob, b->B,
                         b->max_frames, st);
@@ -740,17 +770,18 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
     const int nl = d->n_layers;
     // :99-103  scatter + Assembler + ISTFT  (out-of-band part is the constant `oob`)
     SynthLaunch S;
-    S.plan = e->plan->dev; S.frame_off = b->d_frame_off; S.B = b->B; S.max_frames = b->max_frames;
+    S.plan = e->plan->dev; S.frame_off = b->d_frame_off; S.B = b->B; S.max_frames = b->max_frames; S.run_blocks = b->synth_run;
     S.amp = e->coef; S.ph = e->P; S.out = e->yraw; S.add = e->oob; S.pmax = e->pmaxY; S.pstride = b->pstride;
-    launch_synth(S, st);
+    const int dsp = e->cfg.dsp_path;
+    run_synth(S, dsp, st);
     LAUNCHCHK(); PROF(K_SYNTH);
     // normalise x2 + STFT + |.| on the band (:104 zeroes the rest, so it is never computed)
     AnalysisLaunch L;
     L.plan = e->plan->dev; L.frame_off = b->d_frame_off; L.B = b->B; L.max_frames = b->max_frames;
     L.sig = e->yraw; L.sig_off = b->d_out_off; L.sig_len = b->d_out_len;
     L.pmax = e->pmaxY; L.pcount = b->d_pc_syn; L.pstride = b->pstride; L.double_norm = 1;
-    L.mag = e->mag; L.unit = e->U; L.unit_default = 0.f;
-    launch_analysis(L, st);
+    L.mag = e->mag; L.unit = e->U; L.unit_default = 0.f; L.write_pad = 0;
+    run_analysis(L, dsp, st);
     LAUNCHCHK(); PROF(K_ANALYSIS);
     // :107 detector forward
     const int nwm = clip_tile_groups(b);
@@ -821,10 +852,10 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
     LAUNCHCHK(); PROF(K_GEMM);
     // backward through |.|, STFT, reflect padding
     SynthLaunch SA;
-    SA.plan = e->plan->dev; SA.frame_off = b->d_frame_off; SA.B = b->B; SA.max_frames = b->max_frames;
+    SA.plan = e->plan->dev; SA.frame_off = b->d_frame_off; SA.B = b->B; SA.max_frames = b->max_frames; SA.run_blocks = b->synth_run;
     SA.amp = e->gmag; SA.ph = e->U; SA.out = e->gy; SA.adjoint = 1; SA.yraw = e->yraw; SA.pmax_in = e->pmaxY;
-    SA.pcount = b->d_pc_syn; SA.pdot = e->pdot; SA.pstride = b->pstride;
-    launch_synth(SA, st);
+    SA.pcount = b->d_pc_syn; SA.pdot = e->pdot; SA.pstride = b->pstride; SA.gpad = e->gpad;
+    run_synth(SA, dsp, st);
     LAUNCHCHK(); PROF(K_SYNTH_ADJ);
     // backward through the normalisers, ISTFT and the assembler; :112-117 NAdam + clamp
     AnalysisLaunch LA;
@@ -836,7 +867,8 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
     LA.improved = e->improved; LA.sched = e->sched; LA.sched_len = e->cfg.num_iterations + 1; LA.step = e->step;
     LA.grad_out = grad_out; LA.do_step = do_step;
     memcpy(LA.hyp, e->hyp, sizeof(LA.hyp));
-    launch_analysis(LA, st);
+    LA.gpad = e->gpad;
+    run_analysis(LA, dsp, st);
     LAUNCHCHK(); PROF(K_ANALYSIS_ADJ);
     return AWARE_OK;
 }
@@ -916,9 +948,9 @@ extern "C" int aware_embed_finish(aware_embed* e, const float* rescale, float* o
     hipStream_t st = (hipStream_t)stream;
     const aware_batch* b = e->b;
     SynthLaunch S;
-    S.plan = e->plan->dev; S.frame_off = b->d_frame_off; S.B = b->B; S.max_frames = b->max_frames;
+    S.plan = e->plan->dev; S.frame_off = b->d_frame_off; S.B = b->B; S.max_frames = b->max_frames; S.run_blocks = b->synth_run;
     S.amp = e->best; S.ph = e->P; S.out = e->yraw; S.add = e->oob; S.pmax = e->pmaxY; S.pstride = b->pstride;
-    launch_synth(S, st);
+    run_synth(S, e->cfg.dsp_path, st);
     LAUNCHCHK();
     launch_finish(e->yraw, b->d_frame_off, e->pmaxY, b->d_pc_syn, b->pstride, rescale, out, b->d_out_off, b->B,
                   b->max_frames, st);

@@ -119,9 +119,10 @@ __device__ __forceinline__ int ola_envelope_index(int p, int T) {
     return min(max(idx, 0), 2303);
 }
 
-// balanced split of `nblk` hop blocks into nseg = ceil(nblk/13) segments
-__device__ __forceinline__ void synth_segment(int nblk, int seg, int& nseg, int& jb0, int& jb1) {
-    nseg = (nblk + kSynthBlocks - 1) / kSynthBlocks;
+// balanced split of `nblk` hop blocks into nseg = ceil(nblk / run_blocks) segments (run_blocks <= kSynthBlocks: the
+// batch's choice, aware_batch::synth_run -- shorter runs when few clips would leave the chip empty)
+__device__ __forceinline__ void synth_segment(int nblk, int seg, int run_blocks, int& nseg, int& jb0, int& jb1) {
+    nseg = (nblk + run_blocks - 1) / run_blocks;
     if (nseg < 1) nseg = 1;
     int base = nblk / nseg, rem = nblk % nseg;
     jb0 = seg * base + (seg < rem ? seg : rem);

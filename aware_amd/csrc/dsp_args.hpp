@@ -1,0 +1,80 @@
+// Argument blocks and small device helpers shared by the workgroup-staged DSP kernels (dsp_kernels.hip) and the
+// streaming wave kernels (dsp_stream.hip).
+#pragma once
+#include "common.hpp"
+
+namespace aware {
+
+// 1-ulp hardware reciprocal / square root (v_rcp_f32, v_sqrt_f32) instead of the ~10-instruction IEEE expansions
+// hipcc emits for `/` and sqrtf: a quarter of the analysis kernels' vector instructions were division fix-ups.
+// Where the reference divides by a per-clip scalar (waveform.py:18-19) the scalar's reciprocal is still an IEEE
+// division, taken once per thread; the per-sample operation becomes a multiplication (<= 1 ulp from the quotient).
+#ifndef AWARE_EXACT_DIV
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+#else
+__device__ __forceinline__ float fast_rcp(float x) { return 1.0f / x; }
+__device__ __forceinline__ float fast_sqrt(float x) { return sqrtf(x); }
+#endif
+
+enum { AN_NORM = 0, AN_ADJ = 1 };
+enum { SY_FWD = 0, SY_ADJ = 1 };
+
+struct AnalysisArgs {
+    PlanDev plan;
+    const int* frame_off;             // [B+1]
+    const float* sig;                 // signal base
+    const int* sig_off;               // [B] float offset of clip b in `sig`
+    const int* sig_len;               // [B] samples (reflect padding uses this length)
+    const unsigned long long* pmax;   // [B][pstride] partial |y| maxima (or null: no normalisation)
+    const int* pcount;                // [B] number of partials
+    int pstride;
+    int double_norm;                  // AN_NORM: 1 = y/m/m2, 0 = y/m
+    float unit_default;               // phasor written where |X| == 0 (x component)
+    float* mag;                       // [NF][kFS] or null
+    cf* unit;                         // [NF][kFS] or null
+    cf* full;                         // [NF][520] full complex spectrum (k = 0..512) or null
+    // AN_ADJ only (adjoint of synthesis + fused optimiser step)
+    const float* yraw;                // un-normalised synthesis output (same offsets as sig)
+    const double* pdot;               // [B][pstride] partial sums of g*y2
+    const cf* phasor;                 // [NF][kFS] unit phasor of the original phase
+    float* coef;                      // [NF][kFS] variables
+    float* mom;                       // exp_avg
+    float* vel;                       // exp_avg_sq
+    const float* lo;
+    const float* hi;
+    float* best;
+    const int* improved;              // [B]
+    const float4* sched;              // per step {c_grad, c_mom, bias_correction2, 0}
+    int sched_len;                    // entries in `sched` (the step index is clamped to it)
+    const int* step;                  // device step counter
+    float* grad_out;                  // optional [NF][kFS] raw gradient (tests)
+    int do_step;                      // 0: only write grad_out
+    float4 hyp;                       // {1-beta1, beta2, 1-beta2, eps}
+    // streaming wave kernels only (dsp_stream.hip)
+    const float* gpad;                // AN_ADJ: [B][2][512] reflect-pad parts of the synthesis adjoint, folded in on load
+    int write_pad;                    // AN_NORM: also write the zero tail (columns nband..255) of mag / unit rows
+};
+
+
+struct SynthArgs {
+    PlanDev plan;
+    const int* frame_off;
+    const float* amp;                 // [NF][kFS] real amplitude (coefficients or dL/dmag)
+    const cf* ph;                     // [NF][kFS] unit phasor
+    const cf* full;                   // [NF][520] full complex spectrum (SY_FWD only) or null
+    float* out;                       // per-clip signals at offset 256*(frame_off[b]-b)
+    const float* add;                 // SY_FWD: constant out-of-band part added to the output (or null)
+    unsigned long long* pmax;         // SY_FWD: [B][pstride] partial maxima out
+    int pstride;
+    // SY_ADJ
+    const float* yraw;                // forward synthesis output
+    const unsigned long long* pmax_in;
+    const int* pcount;
+    double* pdot;                     // [B][pstride] partial sums of g2*y2 out
+    float* gpad;                      // streaming SY_ADJ: [B][2][512] reflect-pad parts out (left pads, right pads)
+    int run_blocks;                   // hop blocks per run / workgroup segment (<= kSynthBlocks)
+};
+
+
+}  // namespace aware

@@ -16,21 +16,10 @@
 //                embedding/multibit_embedder.py:95-111, written out by hand; the
 //                NAdam + clamp + best-snapshot epilogue replaces :112-122.
 #include "common.hpp"
+#include "dsp_args.hpp"
 #include "kernels.h"
 
 namespace aware {
-
-// 1-ulp hardware reciprocal / square root (v_rcp_f32, v_sqrt_f32) instead of the ~10-instruction IEEE expansions
-// hipcc emits for `/` and sqrtf: a quarter of the analysis kernels' vector instructions were division fix-ups.
-// Where the reference divides by a per-clip scalar (waveform.py:18-19) the scalar's reciprocal is still an IEEE
-// division, taken once per thread; the per-sample operation becomes a multiplication (<= 1 ulp from the quotient).
-#ifndef AWARE_EXACT_DIV
-__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
-#else
-__device__ __forceinline__ float fast_rcp(float x) { return 1.0f / x; }
-__device__ __forceinline__ float fast_sqrt(float x) { return sqrtf(x); }
-#endif
 
 // ---------------------------------------------------------------------------------
 // |x| maximum per clip, as per-segment partials (4096 samples per workgroup)
@@ -57,40 +46,6 @@ __global__ __launch_bounds__(kThreads) void absmax_partial_kernel(const float* _
 // ---------------------------------------------------------------------------------
 // Analysis: frames -> windowed real FFT -> epilogue
 // ---------------------------------------------------------------------------------
-enum { AN_NORM = 0, AN_ADJ = 1 };
-
-struct AnalysisArgs {
-    PlanDev plan;
-    const int* frame_off;             // [B+1]
-    const float* sig;                 // signal base
-    const int* sig_off;               // [B] float offset of clip b in `sig`
-    const int* sig_len;               // [B] samples (reflect padding uses this length)
-    const unsigned long long* pmax;   // [B][pstride] partial |y| maxima (or null: no normalisation)
-    const int* pcount;                // [B] number of partials
-    int pstride;
-    int double_norm;                  // AN_NORM: 1 = y/m/m2, 0 = y/m
-    float unit_default;               // phasor written where |X| == 0 (x component)
-    float* mag;                       // [NF][kFS] or null
-    cf* unit;                         // [NF][kFS] or null
-    cf* full;                         // [NF][520] full complex spectrum (k = 0..512) or null
-    // AN_ADJ only (adjoint of synthesis + fused optimiser step)
-    const float* yraw;                // un-normalised synthesis output (same offsets as sig)
-    const double* pdot;               // [B][pstride] partial sums of g*y2
-    const cf* phasor;                 // [NF][kFS] unit phasor of the original phase
-    float* coef;                      // [NF][kFS] variables
-    float* mom;                       // exp_avg
-    float* vel;                       // exp_avg_sq
-    const float* lo;
-    const float* hi;
-    float* best;
-    const int* improved;              // [B]
-    const float4* sched;              // per step {c_grad, c_mom, bias_correction2, 0}
-    int sched_len;                    // entries in `sched` (the step index is clamped to it)
-    const int* step;                  // device step counter
-    float* grad_out;                  // optional [NF][kFS] raw gradient (tests)
-    int do_step;                      // 0: only write grad_out
-    float4 hyp;                       // {1-beta1, beta2, 1-beta2, eps}
-};
 
 // FULLOUT: write the full one-sided spectrum (generic STFT plug-in) instead of the band outputs
 template <int MODE, bool FULLOUT>
@@ -293,24 +248,6 @@ __global__ __launch_bounds__(kThreads) void analysis_kernel(AnalysisArgs a) {
 // ---------------------------------------------------------------------------------
 // Synthesis: spectrum -> inverse real FFT -> window -> overlap-add -> epilogue
 // ---------------------------------------------------------------------------------
-enum { SY_FWD = 0, SY_ADJ = 1 };
-
-struct SynthArgs {
-    PlanDev plan;
-    const int* frame_off;
-    const float* amp;                 // [NF][kFS] real amplitude (coefficients or dL/dmag)
-    const cf* ph;                     // [NF][kFS] unit phasor
-    const cf* full;                   // [NF][520] full complex spectrum (SY_FWD only) or null
-    float* out;                       // per-clip signals at offset 256*(frame_off[b]-b)
-    const float* add;                 // SY_FWD: constant out-of-band part added to the output (or null)
-    unsigned long long* pmax;         // SY_FWD: [B][pstride] partial maxima out
-    int pstride;
-    // SY_ADJ
-    const float* yraw;                // forward synthesis output
-    const unsigned long long* pmax_in;
-    const int* pcount;
-    double* pdot;                     // [B][pstride] partial sums of g2*y2 out
-};
 
 // INP: 0 = full one-sided spectrum, 1 = band inside bins 1..256 (prefetched), 2 = any band
 template <int MODE, int INP>
@@ -325,7 +262,7 @@ __global__ __launch_bounds__(kThreads) void synth_kernel(SynthArgs a) {
     const int T = a.frame_off[b + 1] - f0;
     const int nblk = T - 1;                     // output hop blocks
     int nseg, jb0, jb1;
-    synth_segment(nblk, blockIdx.x, nseg, jb0, jb1);
+    synth_segment(nblk, blockIdx.x, a.run_blocks, nseg, jb0, jb1);
     if ((int)blockIdx.x >= nseg || T < 1) return;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // wave index is wave-uniform: keep it scalar
@@ -599,7 +536,8 @@ void launch_synth(const SynthLaunch& L, hipStream_t st) {
     a.out = L.out; a.add = L.add; a.pmax = L.pmax; a.pstride = L.pstride;
     a.yraw = L.yraw; a.pmax_in = L.pmax_in; a.pcount = L.pcount; a.pdot = L.pdot;
     int nblk = L.max_frames - 1;
-    int nx = (nblk + kSynthBlocks - 1) / kSynthBlocks;
+    a.run_blocks = (L.run_blocks >= 1 && L.run_blocks <= kSynthBlocks) ? L.run_blocks : kSynthBlocks;
+    int nx = (nblk + a.run_blocks - 1) / a.run_blocks;
     if (nx < 1) nx = 1;
     const bool compact = L.plan.band_lo >= 1 && L.plan.band_lo + L.plan.nband <= 257;
     if (L.adjoint) {

@@ -37,6 +37,10 @@ struct AnalysisLaunch {
     float* grad_out = nullptr;
     int do_step = 0;
     float hyp[4] = {0.1f, 0.999f, 0.001f, 1e-8f};
+    // stream = 1: barrier-free streaming wave kernels (dsp_stream.hip; band inside bins 1..256 only)
+    int stream = 0;
+    const float* gpad = nullptr;      // stream + adjoint: reflect-pad parts written by the streaming synthesis adjoint
+    int write_pad = 1;                // stream, forward: write the zero tail of the mag / unit rows
 };
 struct SynthLaunch {
     PlanDev plan;
@@ -54,11 +58,18 @@ struct SynthLaunch {
     const unsigned long long* pmax_in = nullptr;
     const int* pcount = nullptr;
     double* pdot = nullptr;
+    int stream = 0;
+    float* gpad = nullptr;            // stream + adjoint: [B][2][512] reflect-pad parts out
+    int run_blocks = kSynthBlocks;    // hop blocks per run (aware_batch::synth_run); the partial counts follow it
 };
 void launch_absmax_partials(const float* sig, const int* sig_off, const int* sig_len, unsigned long long* pmax,
                             int pstride, int B, int max_len, hipStream_t st);
 void launch_analysis(const AnalysisLaunch& L, hipStream_t st);
 void launch_synth(const SynthLaunch& L, hipStream_t st);
+// dsp_stream.hip: true when the streaming wave kernels serve this plan (band inside bins 1..256)
+bool stream_supported(const PlanDev& plan);
+void launch_analysis_stream(const AnalysisLaunch& L, hipStream_t st);
+void launch_synth_stream(const SynthLaunch& L, hipStream_t st);
 void launch_embed_prepare(const float* c0, float* coef, float* lo, float* hi, float* mom, float* vel, float* best,
                           float ratio, size_t n, hipStream_t st);
 void launch_oob_residual(const float* audio, const int* in_off, const unsigned long long* pmax, const int* pcount,

@@ -189,9 +189,10 @@ class EmbedSession:
 
     def __init__(self, plan: Plan, det: DetectorWeights, batch: Batch, num_iterations=400, tolerance_db=6.0,
                  loss="push_extremes", lr=0.1, beta1=0.9, beta2=0.999, eps=1e-8, momentum_decay=4e-3,
-                 use_graph=True, conv_pipe="bf16x3", fused_readout=True):
+                 use_graph=True, conv_pipe="bf16x3", fused_readout=True, dsp_path="stream"):
         """conv_pipe: "bf16x3" (default: bf16 matrix pipe, exact three-way operand split) or "f32" (f32-input MFMA);
-        fused_readout=False selects the three-kernel read-out that ragged batches use (aware_embed_config)."""
+        fused_readout=False selects the three-kernel read-out that ragged batches use; dsp_path: "stream" (default:
+        streaming wave kernels) or "staged" (workgroup-staged kernels) for the STFT / iSTFT stages (aware_embed_config)."""
         self.lib = load_library()
         self.plan, self.det, self.batch = plan, det, batch
         if loss not in LOSS_KINDS:
@@ -200,7 +201,7 @@ class EmbedSession:
             raise ValueError(f"Unknown conv_pipe: {conv_pipe}")
         self.cfg = EmbedConfig(int(num_iterations), float(tolerance_db), LOSS_KINDS[loss], lr, beta1, beta2, eps,
                                momentum_decay, int(bool(use_graph)), 0 if conv_pipe == "bf16x3" else 1,
-                               0 if fused_readout else 1)
+                               0 if fused_readout else 1, {"stream": 0, "staged": 1}[dsp_path])
         self.nbytes = self.lib.aware_embed_workspace_bytes(batch.h, det.h)
         self.ws = torch.empty(self.nbytes, dtype=torch.uint8, device=_dev())
         h = C.c_void_p()

@@ -132,6 +132,11 @@ typedef struct aware_embed_config {
      *   path ragged batches take). */
     int conv_pipe;
     int readout;
+    /* dsp_path 0: streaming wave kernels for the framed STFT / iSTFT and their adjoints (csrc/dsp_stream.hip: one wave
+     *   streams a run of frames, overlap-add and frame overlap in registers, no barrier) wherever the band lies inside
+     *   bins 1..256; 1: workgroup-staged kernels (csrc/dsp_kernels.hip: any band; the form the streaming kernels are
+     *   tested against). */
+    int dsp_path;
 } aware_embed_config;
 
 size_t aware_embed_workspace_bytes(const aware_batch* batch, const aware_detector* det);

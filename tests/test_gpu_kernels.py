@@ -533,3 +533,44 @@ def test_config1_44k_golden_on_gpu(rt, plan, det, O):
     assert np.max(np.abs(vals - c["raw_marked"])) < 3 * DRIFT["raw"]
     rel = np.linalg.norm(out_c[::16] - c["out_sample"]) / np.linalg.norm(c["out_sample"])
     assert rel < 3 * DRIFT["out_rel_l2"]
+
+
+@pytest.mark.parametrize("lengths", [[48000] * 3, [16000, 48000, 23456, 513, 1100, 160000], [33000, 64000]])
+def test_stream_vs_staged_dsp_kernels(rt, plan, det, O, lengths):
+    """The streaming wave kernels (dsp_stream.hip, default) against the workgroup-staged kernels (dsp_kernels.hip):
+    same first-iteration loss / prediction / gradient and the same state after a few optimiser steps, to f32 rounding
+    (the two forms add the four overlapping frames of a sample, and the reflect-pad fold, in different orders).
+    Lengths cover the uniform fast path, the shortest legal clip (3 frames), a clip shorter than the envelope tables
+    assume (T = 5), non-multiples of the hop and a 10 s clip."""
+    pairs = [make_clip(90 + i, n) for i, n in enumerate(lengths)]
+    wm = np.stack([O.bits_to_bipolar(p[1]) for p in pairs]).astype(np.float32)
+    batch = rt.Batch(lengths)
+    res = []
+    for path in ("stream", "staged"):
+        sess = rt.EmbedSession(plan, det, batch, use_graph=False, dsp_path=path)
+        sess.begin(batch.pack([p[0] for p in pairs]), torch.from_numpy(wm).cuda())
+        lo, hi = sess.bounds
+        g = sess.gradient().cpu().double()
+        l0, p0 = sess.loss.cpu().numpy().copy(), sess.pred.cpu().numpy().copy()
+        sess.iterate(3)
+        out = sess.finish(None)
+        torch.cuda.synchronize()
+        res.append((g, l0, p0, sess.coef.cpu().double(), sess.loss.cpu().numpy().copy(), out.cpu().double(),
+                    lo.cpu().double(), hi.cpu().double()))
+    (g1, l1, p1, c1, lb1, o1, lo1, hi1), (g0, l0, p0, c0, lb0, o0, lo0, hi0) = res
+    assert bool(torch.isfinite(g1).all()) and bool(torch.isfinite(o1).all())
+    assert float((lo1 - lo0).abs().max()) <= 2e-6 * float(hi0.max()) and float((hi1 - hi0).abs().max()) <= 2e-6 * float(hi0.max())
+    assert np.max(np.abs(l1 - l0)) < 5e-6 and np.max(np.abs(p1 - p0)) < 5e-6
+    emb = O.Embedder()
+    for i, (c, _) in enumerate(pairs):
+        sl = slice(batch.frame_offsets[i], batch.frame_offsets[i + 1])
+        if float(g0[sl].norm()) == 0.0:                          # a single pooled frame: zero variance, zero gradient
+            assert float(g1[sl].abs().max()) == 0.0
+            continue
+        rel = ((g1[sl] - g0[sl]).norm() / g0[sl].norm()).item()
+        print(f"clip {i} (n = {lengths[i]}): stream vs staged gradient rel L2 {rel:.2e}")
+        # clips of a few frames have 2-3 pooled frames per channel: the InstanceNorm of two nearly equal values is
+        # ill-conditioned (both forms are 1e-3..1e-2 from the float64 oracle there, tools/small_clip_check.py)
+        assert rel < (2e-4 if batch.frames[i] >= 8 else 5e-2), (i, rel)
+    assert np.max(np.abs(lb1 - lb0)) < 2e-3
+    assert float((o1 - o0).abs().max()) < 2e-2        # three NAdam steps of lr 0.1 amplify rounding differences
