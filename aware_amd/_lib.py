@@ -13,7 +13,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AWARE_HIP_LIB") or os.path.join(_HERE, "libaware_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["capi.hip", "dsp_kernels.hip", "dsp_stream.hip", "detector_kernels.hip", "gemm_x3.hip", "attack_kernels.hip"]
+SOURCES = ["capi.hip", "dsp_kernels.hip", "dsp_stream.hip", "seam_kernels.hip", "detector_kernels.hip", "gemm_x3.hip", "attack_kernels.hip"]
 
 AWARE_OK = 0
 ERRORS = {-1: "bad argument", -2: "unsupported configuration", -3: "HIP runtime error", -4: "workspace too small"}
@@ -59,7 +59,7 @@ class EmbedConfig(C.Structure):
     _fields_ = [("num_iterations", C.c_int), ("tolerance_db", C.c_float), ("loss", C.c_int),
                 ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("momentum_decay", C.c_float), ("use_graph", C.c_int), ("conv_pipe", C.c_int), ("readout", C.c_int),
-                ("dsp_path", C.c_int)]
+                ("dsp_path", C.c_int), ("l1_weight", C.c_float)]
 
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
@@ -83,6 +83,17 @@ SIGNATURES = {
     "aware_stft": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "aware_istft": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "aware_stft_band": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "aware_stft_bwd": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "aware_istft_bwd": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "aware_detector_backward_workspace_bytes": (_sz, [_vp, _vp]),
+    "aware_detector_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "aware_polar_decompose": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "aware_polar_decompose_bwd": (_i, [_vp, _vp, _vp, _vp, _sz, _vp]),
+    "aware_polar_assemble": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "aware_polar_assemble_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "aware_waveform_normalize_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "aware_nadam_coefficients": (_i, [_i, _f, _f, _f, _f, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "aware_nadam_clamp_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, C.POINTER(C.c_float), _f, _f, _f, _vp]),
     "aware_detector_create": (_i, [C.POINTER(_vp), _vp, _vp, _i, _i, _pi, C.POINTER(_vp), C.POINTER(_vp)]),
     "aware_detector_destroy": (None, [_vp]),
     "aware_detect_workspace_bytes": (_sz, [_vp, _vp]),

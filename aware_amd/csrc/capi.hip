@@ -173,6 +173,13 @@ extern "C" int aware_batch_create(aware_batch** out, int B, const int* n_samples
     for (int rb : {16, 8, 4}) {
         long runs = 0;
         for (int i = 0; i < B; ++i) runs += (n_samples[i] / kHop + rb - 1) / rb;
+        // the staged adjoint folds the reflect pads inside the first / last segment: keep those at >= 3 blocks
+        bool ok = true;
+        for (int i = 0; i < B && ok; ++i) {
+            const int nb = n_samples[i] / kHop, ns = (nb + rb - 1) / rb;
+            if (ns > 1 && nb / ns < 3) ok = false;
+        }
+        if (!ok) continue;
         b->synth_run = rb;
         if (runs >= 3072) break;
     }
@@ -328,6 +335,35 @@ extern "C" int aware_istft(const aware_plan* plan, const aware_batch* b, const v
                       b->max_frames, st);
         LAUNCHCHK();
     }
+    return AWARE_OK;
+}
+
+// ---- backward of the two transforms for the differentiable plug-in seam (interfaces/audio.py:6-9) ----
+extern "C" int aware_stft_bwd(const aware_plan* plan, const aware_batch* b, const void* grad_spec, float* grad_audio,
+                              void* stream) {
+    if (!plan || !b || !grad_spec || !grad_audio) return AWARE_E_BADARG;
+    // the adjoint of the reflect padding is implemented for signals of exactly 256*(T-1) samples (what the
+    // reference's loop feeds its STFT: the iSTFT output, multibit_embedder.py:49-67)
+    for (int i = 0; i < b->B; ++i)
+        if (b->n[i] != b->out_len[i] || b->in_off[i] != b->out_off[i]) return AWARE_E_UNSUPPORTED;
+    SynthLaunch S;
+    S.plan = plan->dev; S.frame_off = b->d_frame_off; S.B = b->B; S.max_frames = b->max_frames; S.run_blocks = b->synth_run;
+    S.full = grad_spec; S.out = grad_audio; S.adjoint = 1; S.pstride = b->pstride;
+    launch_synth(S, (hipStream_t)stream);
+    LAUNCHCHK();
+    return AWARE_OK;
+}
+
+extern "C" int aware_istft_bwd(const aware_plan* plan, const aware_batch* b, const float* grad_audio, void* grad_spec,
+                               void* stream) {
+    if (!plan || !b || !grad_audio || !grad_spec) return AWARE_E_BADARG;
+    AnalysisLaunch L;
+    L.plan = plan->dev; L.frame_off = b->d_frame_off; L.B = b->B; L.max_frames = b->max_frames;
+    L.sig = grad_audio; L.sig_off = b->d_out_off; L.sig_len = b->d_out_len;
+    L.pcount = b->d_pc_syn; L.pstride = b->pstride;
+    L.full = grad_spec; L.adjoint = 1;
+    launch_analysis(L, (hipStream_t)stream);
+    LAUNCHCHK();
     return AWARE_OK;
 }
 
@@ -585,6 +621,110 @@ extern "C" int aware_detect(const aware_plan* plan, const aware_detector* d, con
     return AWARE_OK;
 }
 
+// Detector forward (multibit_detector_net.py:109-140), loss / gradient seed at the read-out, and the backward pass
+// down to dL/d(band magnitudes) (data gradients only: the weights are frozen, multibit_embedder.py:76-77).
+struct DetGradCtx {
+    int pipe = 0, readout = 0;
+    const float* target = nullptr;    // [B][n_bits]: bipolar watermark, or dL/dpred when loss_kind == AWARE_LOSS_EXTERNAL
+    int loss_kind = 0;
+    float* loss = nullptr;            // [B]
+    float* best_loss = nullptr;       // [B] or null (no bookkeeping)
+    int* improved = nullptr;
+    int* step = nullptr;              // device step counter to advance, or null
+    float *d1 = nullptr, *d2 = nullptr;   // gradient ping-pong [NP][maxc]
+    float* gmag = nullptr;            // out: [NF][256]
+    const float* loss_add = nullptr;  // [B] per-clip term added to the loss before the best-loss bookkeeping (L1 part), or null
+};
+static int det_forward_backward(const aware_detector* d, const aware_batch* b, const float* mag, DetBufs& db,
+                                const DetGradCtx& G, hipStream_t st) {
+    const int nl = d->n_layers;
+    const int nwm = clip_tile_groups(b);
+    // one kernel for the last conv block, the BRH head, the loss, their backward and the data gradient of the last
+    // conv (uniform batches, bf16x3 configuration); otherwise split-K GEMM + tail kernel + data-gradient GEMM
+    const int pipe = G.pipe;
+    const bool fused_readout = G.readout == 0 && pipe == 0 && nwm && nl >= 2 && d->lastpk && G.target &&
+                               readout_x3_supported(nwm, d->ch[nl - 1], d->ch[nl]) && d->wpk[nl - 2] &&
+                               gemm_clip_x3_supported(nwm, d->ch[nl - 1], d->ch[nl - 2], d->ch[nl - 2]);
+    int rc = det_forward(d, b, mag, db, st, pipe, fused_readout);
+    if (rc) return rc;
+    float* dA = G.d1;
+    float* dB = G.d2;
+    bool dz_ready = false;      // dA already holds dL/dZ of layer l (fused into the producing kernel)
+    int l_top = nl - 1;         // first layer the backward loop below still has to differentiate
+    if (fused_readout) {
+        launch_readout_x3(db.act[nl - 2], d->ch[nl - 1], db.zpart, d->ch[nl - 1] / 128, d->bias[nl - 1], d->lastTpk,
+                          db.rstd[nl - 2], G.target, db.pred, G.loss, G.best_loss, G.improved, G.step, dA, b->B,
+                          nwm, b->uniform_tp, d->ch[nl], d->nbits, G.loss_kind, st, G.loss_add);
+        dz_ready = true;
+        l_top = nl - 2;
+    } else if (db.tail) {
+        launch_tail(db.zpart, kTailSplit, (size_t)b->NP * d->ch[nl], d->bias[nl - 1], b->d_frame_off, b->d_pool_off,
+                    G.target, db.pred, G.loss, G.best_loss, G.improved, dA, G.step, G.loss_kind, d->nbits, b->B,
+                    b->max_frames / 2, st, G.loss_add);
+        dz_ready = true;
+    } else {
+        launch_head(db.act[nl - 1], b->d_frame_off, b->d_pool_off, G.target, db.pred, G.loss, G.best_loss,
+                    G.improved, dA, G.step, G.loss_kind, d->nbits, b->B, st, G.loss_add);
+    }
+    LAUNCHCHK(); PROF(K_HEAD);
+    for (int l = l_top; l >= 0; --l) {
+        const int ci = d->ch[l], co = d->ch[l + 1];
+        if (!dz_ready) {
+            launch_in_lrelu_bwd(dA, db.act[l], b->d_frame_off, b->d_pool_off, db.rstd[l], co, b->B, b->max_frames / 2, st);
+            LAUNCHCHK(); PROF(K_INLRELU);
+        }
+        if (nwm && l > 0 && ci >= 128) {
+            // data-gradient GEMM whose epilogue is the backward of block l-1's InstanceNorm+LeakyReLU
+            dz_ready = true;
+            if (pipe == 0 && d->wTpk[l] && gemm_clip_x3_supported(nwm, ci, co, co)) {
+                launch_gemm_clip_x3(dA, co, d->wTpk[l], nullptr, dB, ci, b->B, nwm, b->uniform_tp, ci, co, 2,
+                                    db.rstd[l - 1], db.act[l - 1], st);
+                LAUNCHCHK(); PROF(K_GEMM_X3_BWD);
+            } else {
+                launch_gemm_clip(dA, co, d->wT[l], co, nullptr, dB, ci, b->B, nwm, b->uniform_tp, ci, co, 2, db.rstd[l - 1],
+                                 db.act[l - 1], st);
+                LAUNCHCHK(); PROF(K_GEMM_CLIP_BWD);
+            }
+        } else {
+            gemm_plain(pipe, dA, co, d->wT[l], co, d->wTpk[l], nullptr, dB, ci, b->NP, ci, co, st);
+            dz_ready = false;
+            LAUNCHCHK(); PROF(K_GEMM);
+        }
+        float* t = dA; dA = dB; dB = t;
+    }
+    launch_mel_norm_bwd(dA, db.xm, b->d_frame_off, b->d_pool_off, db.mstats, db.gstat, db.mpart, db.mstride, b->B,
+                        b->max_frames, st);
+    LAUNCHCHK(); PROF(K_MELNORM);
+    gemm_plain(pipe, db.xm, 128, d->melB, 128, d->melBpk, nullptr, G.gmag, kFS, b->NF, kFS, 128, st);
+    LAUNCHCHK(); PROF(K_GEMM);
+    return AWARE_OK;
+}
+
+// detector forward + backward for the differentiable plug-in seam: values = net(mag), grad_mag = (d values / d mag)^T grad_values
+extern "C" size_t aware_detector_backward_workspace_bytes(const aware_batch* b, const aware_detector* d) {
+    if (!b || !d) return 0;
+    return det_bytes(b, d) + (size_t)b->NP * d->maxc * sizeof(float) * 2 + (size_t)b->B * 8 * sizeof(float) + 4096;
+}
+extern "C" int aware_detector_backward(const aware_detector* d, const aware_batch* b, const float* mag,
+                                       const float* grad_values, float* values, float* grad_mag, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+    if (!d || !b || !mag || !grad_values || !grad_mag || !workspace) return AWARE_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    Carver c(workspace, workspace_bytes);
+    DetBufs o;
+    carve_det(c, b, d, o);
+    DetGradCtx G;
+    G.d1 = c.take<float>((size_t)b->NP * d->maxc);
+    G.d2 = c.take<float>((size_t)b->NP * d->maxc);
+    G.loss = c.take<float>(b->B);
+    if (!c.ok) return AWARE_E_WORKSPACE;
+    G.target = grad_values; G.loss_kind = AWARE_LOSS_EXTERNAL; G.gmag = grad_mag;
+    int rc = det_forward_backward(d, b, mag, o, G, st);
+    if (rc) return rc;
+    if (values) HIPCHK(hipMemcpyAsync(values, o.pred, (size_t)b->B * d->nbits * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return AWARE_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 struct aware_embed {
     const aware_plan* plan;
@@ -598,6 +738,10 @@ struct aware_embed {
     // signals [NS]
     float *yraw, *oob, *gy;
     float* gpad;          // [B][2][512] reflect-pad parts of the synthesis adjoint (streaming DSP kernels)
+    // loss push_extremes + L1 (EXTENSION): original coefficients, per-run partial sums of |c - c0|, per-clip loss term
+    float* c0 = nullptr;
+    double* pl1 = nullptr;
+    float* l1term = nullptr;
     // gradient ping-pong [NP][maxc]
     float *d1, *d2;
     // scalars
@@ -619,6 +763,7 @@ static size_t embed_bytes(const aware_batch* b, const aware_detector* d, int ite
     bytes += (size_t)b->NF * kFS * sizeof(cf) * 2;
     bytes += (size_t)b->NS * sizeof(float) * 3;
     bytes += (size_t)b->B * 1024 * sizeof(float);
+    bytes += (size_t)b->NF * kFS * sizeof(float) + (size_t)b->B * b->pstride * 8 + (size_t)b->B * sizeof(float) + 1024;   // L1 term
     bytes += (size_t)b->NP * d->maxc * sizeof(float) * 2;
     bytes += (size_t)b->B * (3 * d->nbits + 8) * sizeof(float);
     bytes += (size_t)(iters + 1) * sizeof(float4);
@@ -630,11 +775,72 @@ extern "C" size_t aware_embed_workspace_bytes(const aware_batch* b, const aware_
     return embed_bytes(b, d, 4096);
 }
 
+// torch.optim.NAdam's per-step scalars (torch/optim/nadam.py _single_tensor_nadam): mu_product lives in a float32
+// tensor and is read back with .item()
+static void nadam_coefficients(int s, double lr, double b1, double b2, double md, float& mu_product, float out[3]) {
+    const double bc2 = 1.0 - pow(b2, (double)s);
+    const double mu = b1 * (1.0 - 0.5 * pow(0.96, s * md));
+    const double mu_next = b1 * (1.0 - 0.5 * pow(0.96, (s + 1) * md));
+    mu_product = mu_product * (float)mu;
+    const double mp = (double)mu_product;
+    out[0] = (float)(-lr * (1.0 - mu) / (1.0 - mp));
+    out[1] = (float)((-lr * mu_next) / (1.0 - mp * mu_next));
+    out[2] = (float)bc2;
+}
+extern "C" int aware_nadam_coefficients(int step, float lr, float beta1, float beta2, float momentum_decay,
+                                        float* mu_product_io, float* coef3) {
+    if (step < 1 || !mu_product_io || !coef3) return AWARE_E_BADARG;
+    nadam_coefficients(step, lr, beta1, beta2, momentum_decay, *mu_product_io, coef3);
+    return AWARE_OK;
+}
+extern "C" int aware_nadam_clamp_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* lo,
+                                      const float* hi, size_t n, const float* coef3, float beta1, float beta2, float eps,
+                                      void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !coef3 || n < 1) return AWARE_E_BADARG;
+    launch_nadam_clamp(param, grad, exp_avg, exp_avg_sq, lo, hi, n, coef3[0], coef3[1], coef3[2], beta1, beta2, eps,
+                       (hipStream_t)stream);
+    LAUNCHCHK();
+    return AWARE_OK;
+}
+extern "C" int aware_waveform_normalize_bwd(const float* in, const float* grad_out, float* grad_in, const int* off,
+                                            const int* len, int B, void* stream) {
+    if (!in || !grad_out || !grad_in || !off || !len || B < 1) return AWARE_E_BADARG;
+    launch_normalize_bwd(in, grad_out, grad_in, off, len, B, (hipStream_t)stream);
+    LAUNCHCHK();
+    return AWARE_OK;
+}
+extern "C" int aware_polar_decompose(const void* spec, float* mag, float* phase, size_t n, void* stream) {
+    if (!spec || !mag || n < 1) return AWARE_E_BADARG;
+    launch_polar_decompose(spec, mag, phase, n, (hipStream_t)stream);
+    LAUNCHCHK();
+    return AWARE_OK;
+}
+extern "C" int aware_polar_decompose_bwd(const void* spec, const float* grad_mag, const float* grad_phase, void* grad_spec,
+                                         size_t n, void* stream) {
+    if (!spec || !grad_spec || (!grad_mag && !grad_phase) || n < 1) return AWARE_E_BADARG;
+    launch_polar_decompose_bwd(spec, grad_mag, grad_phase, grad_spec, n, (hipStream_t)stream);
+    LAUNCHCHK();
+    return AWARE_OK;
+}
+extern "C" int aware_polar_assemble(const float* mag, const float* phase, void* spec, size_t n, void* stream) {
+    if (!mag || !phase || !spec || n < 1) return AWARE_E_BADARG;
+    launch_polar_assemble(mag, phase, spec, n, (hipStream_t)stream);
+    LAUNCHCHK();
+    return AWARE_OK;
+}
+extern "C" int aware_polar_assemble_bwd(const float* mag, const float* phase, const void* grad_spec, float* grad_mag,
+                                        float* grad_phase, size_t n, void* stream) {
+    if (!mag || !phase || !grad_spec || (!grad_mag && !grad_phase) || n < 1) return AWARE_E_BADARG;
+    launch_polar_assemble_bwd(mag, phase, grad_spec, grad_mag, grad_phase, n, (hipStream_t)stream);
+    LAUNCHCHK();
+    return AWARE_OK;
+}
+
 extern "C" int aware_embed_create(aware_embed** out, const aware_plan* plan, const aware_detector* det,
                                   const aware_batch* b, const aware_embed_config* cfg, void* workspace,
                                   size_t workspace_bytes, void* stream) {
     if (!out || !plan || !det || !b || !cfg || !workspace) return AWARE_E_BADARG;
-    if (cfg->num_iterations < 1 || cfg->num_iterations > 4096 || cfg->loss < 0 || cfg->loss > 5) return AWARE_E_BADARG;
+    if (cfg->num_iterations < 1 || cfg->num_iterations > 4096 || cfg->loss < 0 || cfg->loss > AWARE_LOSS_PUSH_L1) return AWARE_E_BADARG;
     if (cfg->conv_pipe < 0 || cfg->conv_pipe > 1 || cfg->readout < 0 || cfg->readout > 1) return AWARE_E_BADARG;
     if (cfg->dsp_path < 0 || cfg->dsp_path > 1) return AWARE_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
@@ -657,24 +863,25 @@ extern "C" int aware_embed_create(aware_embed** out, const aware_plan* plan, con
     e->pmaxA = c.take<unsigned long long>((size_t)b->B * b->pstride);
     e->pmaxY = c.take<unsigned long long>((size_t)b->B * b->pstride);
     e->pdot = c.take<double>((size_t)b->B * b->pstride);
+    if (cfg->loss == AWARE_LOSS_PUSH_L1) {
+        // the L1 term lives in the streaming DSP kernels only
+        if (cfg->dsp_path != 0 || !stream_supported(plan->dev)) { delete e; return AWARE_E_UNSUPPORTED; }
+        e->c0 = c.take<float>(nsp);
+        e->pl1 = c.take<double>((size_t)b->B * b->pstride);
+        e->l1term = c.take<float>(b->B);
+    }
     if (!c.ok) { delete e; return AWARE_E_WORKSPACE; }
     // columns nband..255 of every spectral row are padding: zeroed once here, never written by the loop kernels
     HIPCHK(hipMemsetAsync(e->mag, 0, nsp * sizeof(float), st));
     HIPCHK(hipMemsetAsync(e->U, 0, nsp * sizeof(cf), st));
     HIPCHK(hipMemsetAsync(e->gpad, 0, (size_t)b->B * 1024 * sizeof(float), st));
-    // torch.optim.NAdam's per-step scalars (torch/optim/nadam.py _single_tensor_nadam):
-    // mu_product lives in a float32 tensor and is read back with .item()
     std::vector<float4> sc(cfg->num_iterations + 1);
     float mu_product = 1.0f;
-    const double b1 = cfg->beta1, b2 = cfg->beta2, lr = cfg->lr, md = cfg->momentum_decay;
+    const double b1 = cfg->beta1, b2 = cfg->beta2;
     for (int s = 1; s <= cfg->num_iterations; ++s) {
-        double bc2 = 1.0 - pow(b2, (double)s);
-        double mu = b1 * (1.0 - 0.5 * pow(0.96, s * md));
-        double mu_next = b1 * (1.0 - 0.5 * pow(0.96, (s + 1) * md));
-        mu_product = mu_product * (float)mu;
-        double mp = (double)mu_product;
-        sc[s - 1] = make_float4((float)(-lr * (1.0 - mu) / (1.0 - mp)), (float)((-lr * mu_next) / (1.0 - mp * mu_next)),
-                                (float)bc2, 0.f);
+        float c3[3];
+        nadam_coefficients(s, cfg->lr, b1, b2, cfg->momentum_decay, mu_product, c3);
+        sc[s - 1] = make_float4(c3[0], c3[1], c3[2], 0.f);
     }
     sc[cfg->num_iterations] = sc[cfg->num_iterations - 1];
     HIPCHK(hipMemcpyAsync(e->sched, sc.data(), sc.size() * sizeof(float4), hipMemcpyHostToDevice, st));
@@ -755,6 +962,7 @@ extern "C" int aware_embed_begin(aware_embed* e, const float* audio, const float
     const float ratio = (float)pow(10.0, -(double)e->cfg.tolerance_db / 20.0);
     launch_embed_prepare(e->mag, e->coef, e->lo, e->hi, e->mom, e->vel, e->best, ratio, (size_t)b->NF * kFS, st);
     LAUNCHCHK();
+    if (e->c0) HIPCHK(hipMemcpyAsync(e->c0, e->coef, (size_t)b->NF * kFS * sizeof(float), hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(e->target, target, (size_t)b->B * e->det->nbits * sizeof(float), hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemsetAsync(e->step, 0, 4 * sizeof(int), st));
     // best_loss = +inf (0x7F800000)
@@ -767,14 +975,18 @@ extern "C" int aware_embed_begin(aware_embed* e, const float* audio, const float
 static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* grad_out) {
     const aware_batch* b = e->b;
     const aware_detector* d = e->det;
-    const int nl = d->n_layers;
     // :99-103  scatter + Assembler + ISTFT  (out-of-band part is the constant `oob`)
     SynthLaunch S;
     S.plan = e->plan->dev; S.frame_off = b->d_frame_off; S.B = b->B; S.max_frames = b->max_frames; S.run_blocks = b->synth_run;
     S.amp = e->coef; S.ph = e->P; S.out = e->yraw; S.add = e->oob; S.pmax = e->pmaxY; S.pstride = b->pstride;
+    S.c0 = e->c0; S.pl1 = e->pl1;
     const int dsp = e->cfg.dsp_path;
     run_synth(S, dsp, st);
     LAUNCHCHK(); PROF(K_SYNTH);
+    if (e->c0) {
+        launch_l1_reduce(e->pl1, b->d_pc_syn, b->pstride, b->d_frame_off, e->plan->dev.nband, e->cfg.l1_weight, e->l1term, b->B, st);
+        LAUNCHCHK(); PROF(K_MISC);
+    }
     // normalise x2 + STFT + |.| on the band (:104 zeroes the rest, so it is never computed)
     AnalysisLaunch L;
     L.plan = e->plan->dev; L.frame_off = b->d_frame_off; L.B = b->B; L.max_frames = b->max_frames;
@@ -783,73 +995,17 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
     L.mag = e->mag; L.unit = e->U; L.unit_default = 0.f; L.write_pad = 0;
     run_analysis(L, dsp, st);
     LAUNCHCHK(); PROF(K_ANALYSIS);
-    // :107 detector forward
-    const int nwm = clip_tile_groups(b);
-    // one kernel for the last conv block, the BRH head, the loss, their backward and the data gradient of the last
-    // conv (uniform batches, bf16x3 configuration); otherwise split-K GEMM + tail kernel + data-gradient GEMM
-    const int pipe = e->cfg.conv_pipe;
-    const bool fused_readout = e->cfg.readout == 0 && pipe == 0 && nwm && nl >= 2 && d->lastpk && e->target &&
-                               readout_x3_supported(nwm, d->ch[nl - 1], d->ch[nl]) && d->wpk[nl - 2] &&
-                               gemm_clip_x3_supported(nwm, d->ch[nl - 1], d->ch[nl - 2], d->ch[nl - 2]);
-    int rc = det_forward(d, b, e->mag, e->db, st, pipe, fused_readout);
-    if (rc) return rc;
-    // :109 loss, :120-122 best tracking, gradient seed
-    float* dA = e->d1;
-    float* dB = e->d2;
-    int* step_ptr = do_step ? e->step : nullptr;        // the read-out kernel advances the step counter
+    // :107 detector forward, :109 loss, :120-122 best tracking, :111 backward through the detector
+    DetGradCtx G;
+    G.pipe = e->cfg.conv_pipe; G.readout = e->cfg.readout; G.target = e->target; G.loss_kind = e->cfg.loss;
+    G.loss = e->loss; G.d1 = e->d1; G.d2 = e->d2; G.gmag = e->gmag; G.loss_add = e->l1term;
+    G.step = do_step ? e->step : nullptr;               // the read-out kernel advances the step counter
     // aware_embed_gradient (do_step == 0) leaves the best-loss bookkeeping alone: the reference snapshots only
     // inside the optimiser loop (multibit_embedder.py:120-122)
-    float* best_loss = do_step ? e->best_loss : nullptr;
-    int* improved = do_step ? e->improved : nullptr;
-    bool dz_ready = false;      // dA already holds dL/dZ of layer l (fused into the producing kernel)
-    int l_top = nl - 1;         // first layer the backward loop below still has to differentiate
-    if (fused_readout) {
-        launch_readout_x3(e->db.act[nl - 2], d->ch[nl - 1], e->db.zpart, d->ch[nl - 1] / 128, d->bias[nl - 1], d->lastTpk,
-                          e->db.rstd[nl - 2], e->target, e->db.pred, e->loss, best_loss, improved, step_ptr, dA, b->B,
-                          nwm, b->uniform_tp, d->ch[nl], d->nbits, e->cfg.loss, st);
-        dz_ready = true;
-        l_top = nl - 2;
-    } else if (e->db.tail) {
-        launch_tail(e->db.zpart, kTailSplit, (size_t)b->NP * d->ch[nl], d->bias[nl - 1], b->d_frame_off, b->d_pool_off,
-                    e->target, e->db.pred, e->loss, best_loss, improved, dA, step_ptr, e->cfg.loss, d->nbits, b->B,
-                    b->max_frames / 2, st);
-        dz_ready = true;
-    } else {
-        launch_head(e->db.act[nl - 1], b->d_frame_off, b->d_pool_off, e->target, e->db.pred, e->loss, best_loss,
-                    improved, dA, step_ptr, e->cfg.loss, d->nbits, b->B, st);
-    }
-    LAUNCHCHK(); PROF(K_HEAD);
-    // :111 backward through the detector (data gradients only; weights are frozen :76-77)
-    for (int l = l_top; l >= 0; --l) {
-        const int ci = d->ch[l], co = d->ch[l + 1];
-        if (!dz_ready) {
-            launch_in_lrelu_bwd(dA, e->db.act[l], b->d_frame_off, b->d_pool_off, e->db.rstd[l], co, b->B, b->max_frames / 2, st);
-            LAUNCHCHK(); PROF(K_INLRELU);
-        }
-        if (nwm && l > 0 && ci >= 128) {
-            // data-gradient GEMM whose epilogue is the backward of block l-1's InstanceNorm+LeakyReLU
-            dz_ready = true;
-            if (pipe == 0 && d->wTpk[l] && gemm_clip_x3_supported(nwm, ci, co, co)) {
-                launch_gemm_clip_x3(dA, co, d->wTpk[l], nullptr, dB, ci, b->B, nwm, b->uniform_tp, ci, co, 2,
-                                    e->db.rstd[l - 1], e->db.act[l - 1], st);
-                LAUNCHCHK(); PROF(K_GEMM_X3_BWD);
-            } else {
-                launch_gemm_clip(dA, co, d->wT[l], co, nullptr, dB, ci, b->B, nwm, b->uniform_tp, ci, co, 2, e->db.rstd[l - 1],
-                                 e->db.act[l - 1], st);
-                LAUNCHCHK(); PROF(K_GEMM_CLIP_BWD);
-            }
-        } else {
-            gemm_plain(pipe, dA, co, d->wT[l], co, d->wTpk[l], nullptr, dB, ci, b->NP, ci, co, st);
-            dz_ready = false;
-            LAUNCHCHK(); PROF(K_GEMM);
-        }
-        float* t = dA; dA = dB; dB = t;
-    }
-    launch_mel_norm_bwd(dA, e->db.xm, b->d_frame_off, b->d_pool_off, e->db.mstats, e->db.gstat, e->db.mpart,
-                        e->db.mstride, b->B, b->max_frames, st);
-    LAUNCHCHK(); PROF(K_MELNORM);
-    gemm_plain(pipe, e->db.xm, 128, d->melB, 128, d->melBpk, nullptr, e->gmag, kFS, b->NF, kFS, 128, st);
-    LAUNCHCHK(); PROF(K_GEMM);
+    G.best_loss = do_step ? e->best_loss : nullptr;
+    G.improved = do_step ? e->improved : nullptr;
+    int rc = det_forward_backward(d, b, e->mag, e->db, G, st);
+    if (rc) return rc;
     // backward through |.|, STFT, reflect padding
     SynthLaunch SA;
     SA.plan = e->plan->dev; SA.frame_off = b->d_frame_off; SA.B = b->B; SA.max_frames = b->max_frames; SA.run_blocks = b->synth_run;
@@ -867,7 +1023,7 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
     LA.improved = e->improved; LA.sched = e->sched; LA.sched_len = e->cfg.num_iterations + 1; LA.step = e->step;
     LA.grad_out = grad_out; LA.do_step = do_step;
     memcpy(LA.hyp, e->hyp, sizeof(LA.hyp));
-    LA.gpad = e->gpad;
+    LA.gpad = e->gpad; LA.c0 = e->c0; LA.l1_weight = e->cfg.l1_weight;
     run_analysis(LA, dsp, st);
     LAUNCHCHK(); PROF(K_ANALYSIS_ADJ);
     return AWARE_OK;

@@ -119,6 +119,38 @@ __device__ __forceinline__ int ola_envelope_index(int p, int T) {
     return min(max(idx, 0), 2303);
 }
 
+// Per-bit loss term and its derivative at the read-out (embedding/losses.py; kinds as AWARE_LOSS_* in aware_hip.h):
+// 0 push_extremes :38-42, 1 mse :23-25, 2 hinge :12-14, 3 sign :68-70, 4 push_sigmoid :55-59, 5 ber :90-92 (no
+// gradient), 6 push_extremes + L1 on the coefficients (EXTENSION; the L1 part is added by the caller), 7 external:
+// `tg` is dL/dp itself.  inv = 1 / n_bits (the losses average over the bits).
+__device__ __forceinline__ void loss_term(int kind, float p, float tg, float inv, float& lterm, float& dp) {
+    if (kind == 0 || kind == 6) {
+        lterm = ((p - tg) * (p - tg) - 0.1f * fabsf(p)) * inv;
+        dp = (2.f * (p - tg) - 0.1f * ((p > 0.f) ? 1.f : (p < 0.f ? -1.f : 0.f))) * inv;
+    } else if (kind == 1) {
+        lterm = (p - tg) * (p - tg) * inv;
+        dp = 2.f * (p - tg) * inv;
+    } else if (kind == 2) {
+        const float h = 1.f - p * tg;
+        lterm = (h > 0.f ? h : 0.f) * inv;
+        dp = (h > 0.f ? -tg : 0.f) * inv;
+    } else if (kind == 3) {
+        const float h = -p * tg;
+        lterm = (h > 0.f ? h : 0.f) * inv;
+        dp = (h > 0.f ? -tg : 0.f) * inv;
+    } else if (kind == 4) {
+        lterm = ((p - tg) * (p - tg) - 0.1f * fabsf(p - 0.5f)) * inv;
+        dp = (2.f * (p - tg) - 0.1f * ((p > 0.5f) ? 1.f : (p < 0.5f ? -1.f : 0.f))) * inv;
+    } else if (kind == 5) {
+        const float sp = (p > 0.f) ? 1.f : (p < 0.f ? -1.f : 0.f), st_ = (tg > 0.f) ? 1.f : (tg < 0.f ? -1.f : 0.f);
+        lterm = (sp != st_ ? 1.f : 0.f) * inv;
+        dp = 0.f;
+    } else {
+        lterm = 0.f;
+        dp = tg;
+    }
+}
+
 // balanced split of `nblk` hop blocks into nseg = ceil(nblk / run_blocks) segments (run_blocks <= kSynthBlocks: the
 // batch's choice, aware_batch::synth_run -- shorter runs when few clips would leave the chip empty)
 __device__ __forceinline__ void synth_segment(int nblk, int seg, int run_blocks, int& nseg, int& jb0, int& jb1) {

@@ -920,7 +920,7 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ a3,
                                                     const float* __restrict__ target, float* __restrict__ pred,
                                                     float* __restrict__ loss_out, float* __restrict__ best_loss,
                                                     int* __restrict__ improved, float* __restrict__ dA3, int* __restrict__ step,
-                                                    int loss_kind, int nbits) {
+                                                    int loss_kind, int nbits, const float* __restrict__ loss_add) {
     __shared__ float part[4][64], mean[64], dm[64];
     const int b = blockIdx.x, c = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int r0 = pool_off[b], Tp = (frame_off[b + 1] - frame_off[b]) / 2;   // rows are 32-aligned per clip
@@ -939,33 +939,13 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ a3,
         if (target) {
             const float tg = target[b * nbits + c];
             const float inv = 1.0f / (float)nbits;
-            if (loss_kind == 0) {
-                lterm = ((p - tg) * (p - tg) - 0.1f * fabsf(p)) * inv;
-                dp = (2.f * (p - tg) - 0.1f * ((p > 0.f) ? 1.f : (p < 0.f ? -1.f : 0.f))) * inv;
-            } else if (loss_kind == 1) {
-                lterm = (p - tg) * (p - tg) * inv;
-                dp = 2.f * (p - tg) * inv;
-            } else if (loss_kind == 2) {
-                float h = 1.f - p * tg;
-                lterm = (h > 0.f ? h : 0.f) * inv;
-                dp = (h > 0.f ? -tg : 0.f) * inv;
-            } else if (loss_kind == 3) {
-                float h = -p * tg;
-                lterm = (h > 0.f ? h : 0.f) * inv;
-                dp = (h > 0.f ? -tg : 0.f) * inv;
-            } else if (loss_kind == 4) {            // push_sigmoid: mse - 0.1*mean|p - 0.5|  (losses.py:55-59)
-                lterm = ((p - tg) * (p - tg) - 0.1f * fabsf(p - 0.5f)) * inv;
-                dp = (2.f * (p - tg) - 0.1f * ((p > 0.5f) ? 1.f : (p < 0.5f ? -1.f : 0.f))) * inv;
-            } else {                                // ber: mean(sign(p) != sign(t)), no gradient  (losses.py:90-92)
-                const float sp = (p > 0.f) ? 1.f : (p < 0.f ? -1.f : 0.f), st_ = (tg > 0.f) ? 1.f : (tg < 0.f ? -1.f : 0.f);
-                lterm = (sp != st_ ? 1.f : 0.f) * inv;
-                dp = 0.f;
-            }
+            loss_term(loss_kind, p, tg, inv, lterm, dp);
         }
     }
     if (!target) return;
     if (g == 0) {
         float L = wave_sum(lterm);
+        if (loss_add) L += loss_add[b];                          // per-clip term computed elsewhere (L1 on the coefficients)
         if (c == 0) {
             loss_out[b] = L;
             if (best_loss) {                                     // null: gradient-only call, no bookkeeping
@@ -1003,7 +983,8 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ zpa
                                                     const int* __restrict__ pool_off, const float* __restrict__ target,
                                                     float* __restrict__ pred, float* __restrict__ loss_out,
                                                     float* __restrict__ best_loss, int* __restrict__ improved,
-                                                    float* __restrict__ dZ, int* __restrict__ step, int loss_kind, int nbits) {
+                                                    float* __restrict__ dZ, int* __restrict__ step, int loss_kind, int nbits,
+                                                    const float* __restrict__ loss_add) {
     __shared__ float red[4][64], red2[4][64], mean_s[64], dm[64];
     const int b = blockIdx.x, c = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int r0 = pool_off[b], Tp = (frame_off[b + 1] - frame_off[b]) / 2;
@@ -1058,33 +1039,13 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ zpa
         if (target) {
             const float tg = target[b * nbits + c];
             const float inv = 1.0f / (float)nbits;
-            if (loss_kind == 0) {
-                lterm = ((p - tg) * (p - tg) - 0.1f * fabsf(p)) * inv;
-                dp = (2.f * (p - tg) - 0.1f * ((p > 0.f) ? 1.f : (p < 0.f ? -1.f : 0.f))) * inv;
-            } else if (loss_kind == 1) {
-                lterm = (p - tg) * (p - tg) * inv;
-                dp = 2.f * (p - tg) * inv;
-            } else if (loss_kind == 2) {
-                float h = 1.f - p * tg;
-                lterm = (h > 0.f ? h : 0.f) * inv;
-                dp = (h > 0.f ? -tg : 0.f) * inv;
-            } else if (loss_kind == 3) {
-                float h = -p * tg;
-                lterm = (h > 0.f ? h : 0.f) * inv;
-                dp = (h > 0.f ? -tg : 0.f) * inv;
-            } else if (loss_kind == 4) {            // push_sigmoid: mse - 0.1*mean|p - 0.5|  (losses.py:55-59)
-                lterm = ((p - tg) * (p - tg) - 0.1f * fabsf(p - 0.5f)) * inv;
-                dp = (2.f * (p - tg) - 0.1f * ((p > 0.5f) ? 1.f : (p < 0.5f ? -1.f : 0.f))) * inv;
-            } else {                                // ber: mean(sign(p) != sign(t)), no gradient  (losses.py:90-92)
-                const float sp = (p > 0.f) ? 1.f : (p < 0.f ? -1.f : 0.f), st_ = (tg > 0.f) ? 1.f : (tg < 0.f ? -1.f : 0.f);
-                lterm = (sp != st_ ? 1.f : 0.f) * inv;
-                dp = 0.f;
-            }
+            loss_term(loss_kind, p, tg, inv, lterm, dp);
         }
     }
     if (!target) return;
     if (g == 0) {
-        const float L = wave_sum(lterm);
+        float L = wave_sum(lterm);
+        if (loss_add) L += loss_add[b];                          // per-clip term computed elsewhere (L1 on the coefficients)
         if (c == 0) {
             loss_out[b] = L;
             if (best_loss) {                                     // null: gradient-only call, no bookkeeping
@@ -1125,9 +1086,9 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ zpa
 
 void launch_tail(const float* zpart, int nsplit, size_t slab, const float* bias, const int* frame_off, const int* pool_off,
                  const float* target, float* pred, float* loss, float* best_loss, int* improved, float* dZ, int* step,
-                 int loss_kind, int nbits, int B, int max_pooled, hipStream_t st) {
+                 int loss_kind, int nbits, int B, int max_pooled, hipStream_t st, const float* loss_add) {
 #define TL(S_, R_) hipLaunchKernelGGL((tail_kernel<S_, R_>), dim3(B), dim3(256), 0, st, zpart, slab, bias, frame_off, pool_off, \
-                                      target, pred, loss, best_loss, improved, dZ, step, loss_kind, nbits)
+                                      target, pred, loss, best_loss, improved, dZ, step, loss_kind, nbits, loss_add)
     if (max_pooled <= 128) { if (nsplit == 4) TL(4, 32); else TL(1, 32); }
     else { if (nsplit == 4) TL(4, 80); else TL(1, 80); }
 #undef TL
@@ -1293,9 +1254,9 @@ void launch_in_lrelu_bwd(float* dA, const float* A, const int* frame_off, const 
 }
 void launch_head(const float* a3, const int* frame_off, const int* pool_off, const float* target, float* pred, float* loss,
                  float* best_loss, int* improved, float* dA3, int* step, int loss_kind, int nbits, int B,
-                 hipStream_t st) {
+                 hipStream_t st, const float* loss_add) {
     hipLaunchKernelGGL(head_kernel, dim3(B), dim3(256), 0, st, a3, frame_off, pool_off, target, pred, loss, best_loss, improved, dA3,
-                       step, loss_kind, nbits);
+                       step, loss_kind, nbits, loss_add);
 }
 
 }  // namespace aware

@@ -17,6 +17,19 @@ __device__ __forceinline__ float fast_rcp(float x) { return 1.0f / x; }
 __device__ __forceinline__ float fast_sqrt(float x) { return sqrtf(x); }
 #endif
 
+// torch.optim.NAdam single-tensor step (torch/optim/nadam.py _single_tensor_nadam) + clamp to the tolerance box
+// (embedding/multibit_embedder.py:112-117).  c_grad = -lr (1 - mu_t) / (1 - mu_product), c_mom = -lr mu_{t+1} /
+// (1 - mu_product mu_{t+1}), inv_bc2 = 1 / (1 - beta2^t); hyp = {1 - beta1, beta2, 1 - beta2, eps}.
+__device__ __forceinline__ void nadam_clamp_update(float& p, float& mo, float& ve, float g, float blo, float bhi,
+                                                   float c_grad, float c_mom, float inv_bc2, const float4& hyp) {
+    mo = mo + hyp.x * (g - mo);                    // exp_avg.lerp_(grad, 1-beta1)
+    ve = ve * hyp.y + (hyp.z * g) * g;            // mul_(beta2).addcmul_(g, g, 1-beta2)
+    const float rden = fast_rcp(fast_sqrt(ve * inv_bc2) + hyp.w);   // 1 / (sqrt(v / bias_corr2) + eps)
+    p = p + (c_grad * g) * rden;
+    p = p + (c_mom * mo) * rden;
+    p = fminf(fmaxf(p, blo), bhi);
+}
+
 enum { AN_NORM = 0, AN_ADJ = 1 };
 enum { SY_FWD = 0, SY_ADJ = 1 };
 
@@ -54,6 +67,8 @@ struct AnalysisArgs {
     // streaming wave kernels only (dsp_stream.hip)
     const float* gpad;                // AN_ADJ: [B][2][512] reflect-pad parts of the synthesis adjoint, folded in on load
     int write_pad;                    // AN_NORM: also write the zero tail (columns nband..255) of mag / unit rows
+    const float* c0;                  // AN_ADJ, loss push_extremes + L1 (EXTENSION): original coefficients [NF][kFS], else null
+    float l1_weight;                  //   dL/dc += l1_weight * sign(c - c0) / (nband * T)
 };
 
 
@@ -74,6 +89,8 @@ struct SynthArgs {
     double* pdot;                     // [B][pstride] partial sums of g2*y2 out
     float* gpad;                      // streaming SY_ADJ: [B][2][512] reflect-pad parts out (left pads, right pads)
     int run_blocks;                   // hop blocks per run / workgroup segment (<= kSynthBlocks)
+    const float* c0;                  // streaming SY_FWD, L1 term: original coefficients; per-run sums of |amp - c0| go to
+    double* pl1;                      //   pl1[B][pstride] (null: no L1 term)
 };
 
 

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kThreads) void analysis_kernel(AnalysisArgs a) {
         kmax = cn.k;
     }
     float adot = 0.f, smax = 0.f;
-    if (MODE == AN_ADJ) {
+    if (MODE == AN_ADJ && a.pdot) {       // (null: plain ISTFT backward of the plug-in seam, no normaliser behind it)
         // A = sum_j g2[j]*y2[j] (fixed summation order) and the sign of the max sample
         double s = 0.0;
         const double* pd = a.pdot + (size_t)b * a.pstride;
@@ -192,9 +192,18 @@ __global__ __launch_bounds__(kThreads) void analysis_kernel(AnalysisArgs a) {
         wave_sync();
         if (FULLOUT) {
             cf* out = a.full + row * 520;
+            // AN_ADJ: adjoint of irfft (torch.istft's C2R transform): dL/dX[k] = (c_k / 1024) rfft(.)[k] with c_k = 2 on
+            // the interior bins and 1 at DC / Nyquist (whose imaginary parts the transform ignores)
+            const float si = (MODE == AN_ADJ) ? (1.0f / 512.0f) : 1.0f, se = (MODE == AN_ADJ) ? (1.0f / 1024.0f) : 1.0f;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) out[lane + 64 * r] = rfft_split_bin(lane + 64 * r, v[r], s, a.plan.tw1024);
-            if (lane == 0) out[512] = mk(rfft_split_nyquist(s), 0.f);
+            for (int r = 0; r < 8; ++r) {
+                const int k = lane + 64 * r;
+                cf X = rfft_split_bin(k, v[r], s, a.plan.tw1024);
+                const float sk = k == 0 ? se : si;
+                X = mk(X.x * sk, (MODE == AN_ADJ && k == 0) ? 0.f : X.y * sk);
+                out[k] = X;
+            }
+            if (lane == 0) out[512] = mk(rfft_split_nyquist(s) * se, 0.f);
         }
         if (!FULLOUT) {
             // band bins k = band_lo + f, f < nband (<= 256)
@@ -229,12 +238,7 @@ __global__ __launch_bounds__(kThreads) void analysis_kernel(AnalysisArgs a) {
                         if (pre) { mo = preM[r < 5 ? r : 0]; ve = preV[r < 5 ? r : 0]; p = preC[r < 5 ? r : 0];
                                    blo = preL[r < 5 ? r : 0]; bhi = preH[r < 5 ? r : 0]; }
                         else { mo = a.mom[idx]; ve = a.vel[idx]; p = a.coef[idx]; blo = a.lo[idx]; bhi = a.hi[idx]; }
-                        mo = mo + a.hyp.x * (g - mo);                    // exp_avg.lerp_(grad, 1-beta1)
-                        ve = ve * a.hyp.y + (a.hyp.z * g) * g;          // mul_(beta2).addcmul_(g, g, 1-beta2)
-                        const float rden = fast_rcp(fast_sqrt(ve * inv_bc2) + a.hyp.w);   // 1 / (sqrt(v / bias_corr2) + eps)
-                        p = p + (sc.x * g) * rden;
-                        p = p + (sc.y * mo) * rden;
-                        p = fminf(fmaxf(p, blo), bhi);
+                        nadam_clamp_update(p, mo, ve, g, blo, bhi, sc.x, sc.y, inv_bc2, a.hyp);
                         a.mom[idx] = mo; a.vel[idx] = ve; a.coef[idx] = p;
                         if (improved) a.best[idx] = p;
                     }
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(kThreads) void synth_kernel(SynthArgs a) {
 
     ClipNorm cn;
     cn.m = 1.f; cn.m2 = 1.f; cn.k = 0;
-    if (MODE == SY_ADJ) cn = clip_norm_from_partials(a.pmax_in + (size_t)b * a.pstride, a.pcount[b], red);
+    if (MODE == SY_ADJ && a.pmax_in) cn = clip_norm_from_partials(a.pmax_in + (size_t)b * a.pstride, a.pcount[b], red);
 
     // twiddles live in LDS in this kernel (28 VGPRs less per lane -> one more wave per SIMD)
     __shared__ cf tw1s[512];
@@ -343,6 +347,9 @@ __global__ __launch_bounds__(kThreads) void synth_kernel(SynthArgs a) {
                     const int k = lane + 64 * r;
                     cf xk = X[k], xp = X[512 - k];
                     if (k == 0) { xk.y = 0.f; xp.y = 0.f; }      // C2R ignores Im of DC / Nyquist
+                    // adjoint of the forward rfft = 512*irfft on the interior bins; DC / Nyquist are not doubled by
+                    // irfft, so they enter twice as large
+                    if (MODE == SY_ADJ && k == 0) { xk.x *= 2.f; xp.x *= 2.f; }
                     v[r] = irfft_merge_bin(k, xk, xp, a.plan.tw1024);
                 }
             } else if (compact) {
@@ -419,14 +426,15 @@ __global__ __launch_bounds__(kThreads) void synth_kernel(SynthArgs a) {
     } else {
         // adjoint of reflect padding: fold the two 512-sample pads back, then the partial
         // dot product with the normalised forward signal for the normaliser's backward
-        const float* y = a.yraw + sig_offset(a.frame_off, b);
+        // (a.yraw null: plain STFT backward of the plug-in seam -- no normaliser in front, no dot product)
+        const float* y = a.yraw ? a.yraw + sig_offset(a.frame_off, b) : nullptr;
         const float inv_m = 1.0f / cn.m, inv_m2 = 1.0f / cn.m2;
         double acc = 0.0;
         float yv[NOUT];
 #pragma unroll
         for (int it = 0; it < NOUT; ++it) {
             const int j = j0 + tid + kThreads * it;
-            yv[it] = y[j < j1 ? j : j0];
+            yv[it] = y ? y[j < j1 ? j : j0] : 0.f;
         }
 #pragma unroll
         for (int it = 0; it < NOUT; ++it) {
@@ -443,7 +451,7 @@ __global__ __launch_bounds__(kThreads) void synth_kernel(SynthArgs a) {
         acc = wave_sum_d(acc);
         if (lane == 0) dred[wave] = acc;
         __syncthreads();
-        if (tid == 0) a.pdot[(size_t)b * a.pstride + blockIdx.x] = dred[0] + dred[1] + dred[2] + dred[3];
+        if (tid == 0 && a.pdot) a.pdot[(size_t)b * a.pstride + blockIdx.x] = dred[0] + dred[1] + dred[2] + dred[3];
     }
 }
 
@@ -520,7 +528,9 @@ void launch_analysis(const AnalysisLaunch& L, hipStream_t st) {
     a.grad_out = L.grad_out; a.do_step = L.do_step;
     a.hyp = make_float4(L.hyp[0], L.hyp[1], L.hyp[2], L.hyp[3]);
     int nx = (L.max_frames + kFramesPerWG - 1) / kFramesPerWG;
-    if (L.adjoint)
+    if (L.adjoint && L.full)
+        hipLaunchKernelGGL((analysis_kernel<AN_ADJ, true>), grid2(nx, L.B), dim3(kThreads), 0, st, a);
+    else if (L.adjoint)
         hipLaunchKernelGGL((analysis_kernel<AN_ADJ, false>), grid2(nx, L.B), dim3(kThreads), 0, st, a);
     else if (L.full)
         hipLaunchKernelGGL((analysis_kernel<AN_NORM, true>), grid2(nx, L.B), dim3(kThreads), 0, st, a);
@@ -540,7 +550,9 @@ void launch_synth(const SynthLaunch& L, hipStream_t st) {
     int nx = (nblk + a.run_blocks - 1) / a.run_blocks;
     if (nx < 1) nx = 1;
     const bool compact = L.plan.band_lo >= 1 && L.plan.band_lo + L.plan.nband <= 257;
-    if (L.adjoint) {
+    if (L.adjoint && L.full) {
+        hipLaunchKernelGGL((synth_kernel<SY_ADJ, 0>), grid2(nx, L.B), dim3(kThreads), 0, st, a);
+    } else if (L.adjoint) {
         if (compact) hipLaunchKernelGGL((synth_kernel<SY_ADJ, 1>), grid2(nx, L.B), dim3(kThreads), 0, st, a);
         else hipLaunchKernelGGL((synth_kernel<SY_ADJ, 2>), grid2(nx, L.B), dim3(kThreads), 0, st, a);
     } else if (L.full) {

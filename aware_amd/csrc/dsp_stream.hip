@@ -184,6 +184,7 @@ __global__ __launch_bounds__(kSThreads, MODE == AN_ADJ ? 3 : 4) void analysis_st
         improved = a.improved[b];
     }
 
+    const float l1g = (MODE == AN_ADJ && a.c0) ? a.l1_weight / (float)(nband * T) : 0.f;
     float2 raw[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) raw[r] = load_half(kHop * t0 + 128 * r);
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(kSThreads, MODE == AN_ADJ ? 3 : 4) void analysis_st
         const size_t row = (size_t)(f0 + t);
         // operands of the optimiser epilogue do not depend on the transform: request them first
         cf preP[5];
-        float preM[5], preV[5], preC[5], preL[5], preH[5];
+        float preM[5], preV[5], preC[5], preL[5], preH[5], pre0[5];
         if (MODE == AN_ADJ) {
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
@@ -202,7 +203,8 @@ __global__ __launch_bounds__(kSThreads, MODE == AN_ADJ ? 3 : 4) void analysis_st
                 const size_t idx = row * kFS + (size_t)min(max(f, 0), kFS - 1);       // clamped, masked at use
                 preP[r] = a.phasor[idx];
                 if (a.do_step) { preM[r] = a.mom[idx]; preV[r] = a.vel[idx]; preC[r] = a.coef[idx]; preL[r] = a.lo[idx]; preH[r] = a.hi[idx]; }
-                else { preM[r] = preV[r] = preC[r] = preL[r] = preH[r] = 0.f; }
+                else { preM[r] = preV[r] = preL[r] = preH[r] = 0.f; preC[r] = a.c0 ? a.coef[idx] : 0.f; }
+                pre0[r] = a.c0 ? a.c0[idx] : 0.f;
             }
         }
         cf v[8];
@@ -243,17 +245,17 @@ __global__ __launch_bounds__(kSThreads, MODE == AN_ADJ ? 3 : 4) void analysis_st
             } else {
                 // dL/dc = Re(G conj P) with G = (2/N) rfft(.)  [adjoint of irfft on interior bins]
                 const cf P = preP[r];
-                const float g = (X.x * P.x + X.y * P.y) * (1.0f / 512.0f);
+                float g = (X.x * P.x + X.y * P.y) * (1.0f / 512.0f);
+                if (a.c0) {
+                    // EXTENSION: + l1_weight * d/dc mean|c - c0| (mean over the clip's nband * T variables; sign(0) = 0)
+                    const float dc = preC[r] - pre0[r];
+                    g += l1g * ((dc > 0.f) ? 1.f : ((dc < 0.f) ? -1.f : 0.f));
+                }
                 if (a.grad_out) a.grad_out[idx] = g;
                 if (a.do_step) {
                     // torch.optim.NAdam single-tensor step + clamp + best snapshot (multibit_embedder.py:112-122)
                     float mo = preM[r], ve = preV[r], p = preC[r];
-                    mo = mo + a.hyp.x * (g - mo);                    // exp_avg.lerp_(grad, 1-beta1)
-                    ve = ve * a.hyp.y + (a.hyp.z * g) * g;          // mul_(beta2).addcmul_(g, g, 1-beta2)
-                    const float rden = fast_rcp(fast_sqrt(ve * inv_bc2) + a.hyp.w);   // 1 / (sqrt(v / bias_corr2) + eps)
-                    p = p + (sc.x * g) * rden;
-                    p = p + (sc.y * mo) * rden;
-                    p = fminf(fmaxf(p, preL[r]), preH[r]);
+                    nadam_clamp_update(p, mo, ve, g, preL[r], preH[r], sc.x, sc.y, inv_bc2, a.hyp);
                     a.mom[idx] = mo; a.vel[idx] = ve; a.coef[idx] = p;
                     if (improved) a.best[idx] = p;
                 }
@@ -347,6 +349,7 @@ __global__ __launch_bounds__(kSThreads, 4) void synth_stream_kernel(SynthArgs a)
     for (int q = 0; q < 6; ++q) acc[q] = make_float2(0.f, 0.f);
     unsigned long long best = 0;
     double dot = 0.0;
+    float l1 = 0.f;                          // sum of |amp - c0| over the band bins of the frames this run owns
     if (t_lo <= T - 1) load_band(t_lo);
 
 #pragma unroll 1
@@ -364,6 +367,16 @@ __global__ __launch_bounds__(kSThreads, 4) void synth_stream_kernel(SynthArgs a)
         }
         float2 c[8];
         if (t <= T - 1) {
+            if (MODE == SY_FWD && a.pl1 && ((t >= jb0 && t < jb1) || (last && t == T - 1))) {
+                // own bins of the slots: k = lane + 64 r <= 256 (r < 4, and lane 0 of r = 4)
+                const float* C0 = a.c0 + (size_t)(f0 + t) * kFS;
+#pragma unroll
+                for (int r = 0; r < 5; ++r) {
+                    const int f = lane + 64 * r - band_lo;
+                    const float cv = C0[min(max(f, 0), kFS - 1)];
+                    if (f >= 0 && f < nband && (r < 4 || lane == 0)) l1 += fabsf(inA[r] - cv);
+                }
+            }
             cf v[8];
             // irfft merge with one of the two inputs known to be zero (band inside bins 1..256):
             //   k < 256:  Z[k] = X[k] * (1 + i conj W^k)/2        k >= 256:  Z[k] = conj(X[512-k]) * (1 - i conj W^k)/2
@@ -453,10 +466,28 @@ __global__ __launch_bounds__(kSThreads, 4) void synth_stream_kernel(SynthArgs a)
             best = wave_max64(best);
             if (lane == 0) a.pmax[(size_t)b * a.pstride + run] = best;
         }
+        if (a.pl1) {
+            const double tot = wave_sum_d((double)l1);
+            if (lane == 0) a.pl1[(size_t)b * a.pstride + run] = tot;
+        }
     } else {
         dot = wave_sum_d(dot);
         if (lane == 0) a.pdot[(size_t)b * a.pstride + run] = dot;
     }
+}
+
+// L1 part of the loss push_extremes + L1 (EXTENSION): l1term[b] = weight * sum_runs pl1[b][run] / (nband * T_b)
+__global__ __launch_bounds__(64) void l1_reduce_kernel(const double* __restrict__ pl1, const int* __restrict__ pcount, int pstride,
+                                                        const int* __restrict__ frame_off, int nband, float weight,
+                                                        float* __restrict__ l1term) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const double s = dot_wave(pl1 + (size_t)b * pstride, pcount[b], lane);
+    const int T = frame_off[b + 1] - frame_off[b];
+    if (lane == 0) l1term[b] = weight * (float)(s / (double)(nband * T));
+}
+void launch_l1_reduce(const double* pl1, const int* pcount, int pstride, const int* frame_off, int nband, float weight,
+                      float* l1term, int B, hipStream_t st) {
+    hipLaunchKernelGGL(l1_reduce_kernel, dim3(B), dim3(64), 0, st, pl1, pcount, pstride, frame_off, nband, weight, l1term);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -478,6 +509,7 @@ void launch_analysis_stream(const AnalysisLaunch& L, hipStream_t st) {
     a.grad_out = L.grad_out; a.do_step = L.do_step;
     a.hyp = make_float4(L.hyp[0], L.hyp[1], L.hyp[2], L.hyp[3]);
     a.gpad = L.gpad; a.write_pad = L.write_pad;
+    a.c0 = L.c0; a.l1_weight = L.l1_weight;
     // frames per wave: long runs re-use three quarters of every frame from registers; short runs fill the chip when
     // the batch is small (a run start costs 8 loads per lane, every further frame 2)
     int R = 4;
@@ -497,6 +529,7 @@ void launch_synth_stream(const SynthLaunch& L, hipStream_t st) {
     a.amp = L.amp; a.ph = (const cf*)L.ph; a.full = nullptr;
     a.out = L.out; a.add = L.add; a.pmax = L.pmax; a.pstride = L.pstride;
     a.yraw = L.yraw; a.pmax_in = L.pmax_in; a.pcount = L.pcount; a.pdot = L.pdot; a.gpad = L.gpad;
+    a.c0 = L.c0; a.pl1 = (L.c0 && L.pl1) ? L.pl1 : nullptr;
     const int nblk = L.max_frames - 1;
     a.run_blocks = (L.run_blocks >= 1 && L.run_blocks <= kSynthBlocks) ? L.run_blocks : kSynthBlocks;
     int runs = (nblk + a.run_blocks - 1) / a.run_blocks;

@@ -583,7 +583,7 @@ __global__ __launch_bounds__(512) void readout_x3_kernel(const float* __restrict
                                                           float* __restrict__ loss_out, float* __restrict__ best_loss,
                                                           int* __restrict__ improved, int* __restrict__ step,
                                                           float* __restrict__ dZ, int Tp, int C, int nbits, int loss_kind,
-                                                          int G, int ntiles) {
+                                                          int G, int ntiles, const float* __restrict__ loss_add) {
     constexpr int MT = 2 * RG;
     constexpr int FRAG = 1024;
     constexpr int KSC = 2;                           // K32 steps of the data-gradient GEMM (C <= 64)
@@ -701,33 +701,13 @@ __global__ __launch_bounds__(512) void readout_x3_kernel(const float* __restrict
             p = tanhf(mean_s[2 * c] - mean_s[2 * c + 1]);
             const float tg = target[clip * nbits + c];
             const float inv = 1.0f / (float)nbits;
-            if (loss_kind == 0) {                       // push_extremes (losses.py:38-42)
-                lterm = ((p - tg) * (p - tg) - 0.1f * fabsf(p)) * inv;
-                dp = (2.f * (p - tg) - 0.1f * ((p > 0.f) ? 1.f : (p < 0.f ? -1.f : 0.f))) * inv;
-            } else if (loss_kind == 1) {                // mse
-                lterm = (p - tg) * (p - tg) * inv;
-                dp = 2.f * (p - tg) * inv;
-            } else if (loss_kind == 2) {                // hinge
-                const float hh = 1.f - p * tg;
-                lterm = (hh > 0.f ? hh : 0.f) * inv;
-                dp = (hh > 0.f ? -tg : 0.f) * inv;
-            } else if (loss_kind == 3) {                // sign
-                const float hh = -p * tg;
-                lterm = (hh > 0.f ? hh : 0.f) * inv;
-                dp = (hh > 0.f ? -tg : 0.f) * inv;
-            } else if (loss_kind == 4) {                // push_sigmoid (losses.py:55-59)
-                lterm = ((p - tg) * (p - tg) - 0.1f * fabsf(p - 0.5f)) * inv;
-                dp = (2.f * (p - tg) - 0.1f * ((p > 0.5f) ? 1.f : (p < 0.5f ? -1.f : 0.f))) * inv;
-            } else {                                    // ber: no gradient (losses.py:90-92)
-                const float sp = (p > 0.f) ? 1.f : (p < 0.f ? -1.f : 0.f), st_ = (tg > 0.f) ? 1.f : (tg < 0.f ? -1.f : 0.f);
-                lterm = (sp != st_ ? 1.f : 0.f) * inv;
-                dp = 0.f;
-            }
+            loss_term(loss_kind, p, tg, inv, lterm, dp);
             const float dpre = dp * (1.f - p * p);      // tanh'
             dm[2 * c] = dpre; dm[2 * c + 1] = -dpre;
             if (g == 0) pred[clip * nbits + c] = p;
         }
-        const float L = wave_sum(lterm);
+        float L = wave_sum(lterm);
+        if (loss_add) L += loss_add[clip];                       // per-clip term computed elsewhere (L1 on the coefficients)
         if (g == 0 && lane == 0) {
             loss_out[clip] = L;
             if (best_loss) {                                     // null: gradient-only call, no bookkeeping
@@ -879,12 +859,13 @@ bool readout_x3_supported(int nwm, int ci, int C) { return nwm >= 1 && nwm <= 4 
 // WTpk: x3_pack of the last conv's transposed weights ([ci][C], k zero-padded to 64)
 void launch_readout_x3(const float* hin, int ci, const float* zpart, int nslab, const float* bias, const void* WTpk,
                        const float* rstd_prev, const float* target, float* pred, float* loss, float* best_loss, int* improved,
-                       int* step, float* dZ, int B, int nwm, int Tp, int C, int nbits, int loss_kind, hipStream_t st) {
+                       int* step, float* dZ, int B, int nwm, int Tp, int C, int nbits, int loss_kind, hipStream_t st,
+                       const float* loss_add) {
     const int G = ci / 256, nc = (C + 15) / 16;
     const size_t slab_stride = (size_t)B * 32 * nwm * C;
 #define RK(M_, N_) hipLaunchKernelGGL((readout_x3_kernel<M_, N_>), dim3(B * G), dim3(512), 0, st, hin, ci, zpart, nslab, slab_stride, \
                                       bias, (const u32x4*)WTpk, rstd_prev, target, pred, loss, best_loss, improved, step, dZ, Tp, C, \
-                                      nbits, loss_kind, G, B * G)
+                                      nbits, loss_kind, G, B * G, loss_add)
 #define RN(M_) switch (nc) { case 1: RK(M_, 1); break; case 2: RK(M_, 2); break; case 3: RK(M_, 3); break; default: RK(M_, 4); break; }
     switch (nwm) { case 1: RN(1) break; case 2: RN(2) break; case 3: RN(3) break; default: RN(4) break; }
 #undef RN

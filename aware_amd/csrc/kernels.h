@@ -41,6 +41,8 @@ struct AnalysisLaunch {
     int stream = 0;
     const float* gpad = nullptr;      // stream + adjoint: reflect-pad parts written by the streaming synthesis adjoint
     int write_pad = 1;                // stream, forward: write the zero tail of the mag / unit rows
+    const float* c0 = nullptr;        // stream + adjoint: L1 term on the coefficients (loss push_extremes + L1)
+    float l1_weight = 0.f;
 };
 struct SynthLaunch {
     PlanDev plan;
@@ -61,6 +63,8 @@ struct SynthLaunch {
     int stream = 0;
     float* gpad = nullptr;            // stream + adjoint: [B][2][512] reflect-pad parts out
     int run_blocks = kSynthBlocks;    // hop blocks per run (aware_batch::synth_run); the partial counts follow it
+    const float* c0 = nullptr;        // stream, forward: per-run sums of |amp - c0| into pl1 (L1 term)
+    double* pl1 = nullptr;
 };
 void launch_absmax_partials(const float* sig, const int* sig_off, const int* sig_len, unsigned long long* pmax,
                             int pstride, int B, int max_len, hipStream_t st);
@@ -70,6 +74,9 @@ void launch_synth(const SynthLaunch& L, hipStream_t st);
 bool stream_supported(const PlanDev& plan);
 void launch_analysis_stream(const AnalysisLaunch& L, hipStream_t st);
 void launch_synth_stream(const SynthLaunch& L, hipStream_t st);
+// l1term[b] = weight * (sum of the clip's pl1 partials) / (nband * T_b): the L1 part of the loss push_extremes + L1
+void launch_l1_reduce(const double* pl1, const int* pcount, int pstride, const int* frame_off, int nband, float weight,
+                      float* l1term, int B, hipStream_t st);
 void launch_embed_prepare(const float* c0, float* coef, float* lo, float* hi, float* mom, float* vel, float* best,
                           float ratio, size_t n, hipStream_t st);
 void launch_oob_residual(const float* audio, const int* in_off, const unsigned long long* pmax, const int* pcount,
@@ -104,7 +111,8 @@ void launch_gemm_clip_x3(const float* A, int lda, const void* Bpk, const float* 
 bool readout_x3_supported(int nwm, int ci, int C);
 void launch_readout_x3(const float* hin, int ci, const float* zpart, int nslab, const float* bias, const void* WTpk,
                        const float* rstd_prev, const float* target, float* pred, float* loss, float* best_loss, int* improved,
-                       int* step, float* dZ, int B, int nwm, int Tp, int C, int nbits, int loss_kind, hipStream_t st);
+                       int* step, float* dZ, int B, int nwm, int Tp, int C, int nbits, int loss_kind, hipStream_t st,
+                       const float* loss_add = nullptr);
 // mel block: InstanceNorm over time, per-clip GlobalStandardize, AvgPool(2,2)
 void launch_mel_norm_fwd(const float* xm, const int* frame_off, const int* pool_off, float* x0, float* stats,
                          float* gstat, float* part, int pstride, int B, int max_frames, hipStream_t st);
@@ -119,12 +127,22 @@ void launch_in_lrelu_bwd(float* dA, const float* A, const int* frame_off, const 
 // BRH + loss + dL/dA3; also best-loss tracking
 void launch_head(const float* a3, const int* frame_off, const int* pool_off, const float* target, float* pred, float* loss,
                  float* best_loss, int* improved, float* dA3, int* step, int loss_kind, int nbits, int B,
-                 hipStream_t st);
+                 hipStream_t st, const float* loss_add = nullptr);
 void launch_gemm_nt_splitk(const float* A, int lda, const float* Bt, int ldb, float* Cpart, int ldc, int M, int N, int K,
                            int ksplit, hipStream_t st);
 void launch_tail(const float* zpart, int nsplit, size_t slab, const float* bias, const int* frame_off, const int* pool_off,
                  const float* target, float* pred, float* loss, float* best_loss, int* improved, float* dZ, int* step,
-                 int loss_kind, int nbits, int B, int max_pooled, hipStream_t st);
+                 int loss_kind, int nbits, int B, int max_pooled, hipStream_t st, const float* loss_add = nullptr);
+
+// ---- seam_kernels.hip: element-wise pieces of the differentiable plug-in seam -----------------------------
+void launch_polar_decompose(const void* spec, float* mag, float* phase, size_t n, hipStream_t st);
+void launch_polar_decompose_bwd(const void* spec, const float* gmag, const float* gphase, void* gspec, size_t n, hipStream_t st);
+void launch_polar_assemble(const float* mag, const float* phase, void* spec, size_t n, hipStream_t st);
+void launch_polar_assemble_bwd(const float* mag, const float* phase, const void* gspec, float* gmag, float* gphase, size_t n,
+                               hipStream_t st);
+void launch_normalize_bwd(const float* x, const float* g, float* dx, const int* off, const int* len, int B, hipStream_t st);
+void launch_nadam_clamp(float* p, const float* g, float* m, float* v, const float* lo, const float* hi, size_t n, float c_grad,
+                        float c_mom, float bias_corr2, float beta1, float beta2, float eps, hipStream_t st);
 
 // ---- attack_kernels.hip -----------------------------------------------------------------
 void launch_pcm_quantize(const float* in, float* out, const int* off, const int* len, const unsigned long long* pmax,

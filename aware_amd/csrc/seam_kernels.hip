@@ -1,0 +1,136 @@
+// Element-wise kernels of the differentiable plug-in seam (gfx950): what the reference's plug-in objects and its
+// optimiser do one torch op at a time between the transforms --
+//   STFTDecomposer  abs / angle                 utils/audio/stft.py:54-55
+//   STFTAssembler   mag * exp(i phase)          utils/audio/stft.py:61-62
+//   WaveformNormalizer backward                 utils/audio/waveform.py:18-19 (gradient flows through the max)
+//   NAdam step + clamp to the tolerance box     embedding/multibit_embedder.py:112-117 (torch.optim.NAdam)
+// with their backward passes, so that the reference-shaped loop (plug-in lists + autograd, aware_amd/utils/audio/
+// plugins.py) runs on the same arithmetic as the fused hot loop.  All HBM-bound streaming kernels.
+#include "common.hpp"
+#include "dsp_args.hpp"
+#include "kernels.h"
+
+namespace aware {
+
+__global__ __launch_bounds__(256) void polar_decompose_kernel(const cf* __restrict__ spec, float* __restrict__ mag,
+                                                              float* __restrict__ phase, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const cf s = spec[i];
+        mag[i] = hypotf(s.x, s.y);
+        if (phase) phase[i] = atan2f(s.y, s.x);
+    }
+}
+// d|S| = Re(conj(S) dS)/|S| (0 at S = 0, torch's sgn convention); d angle = Im(conj(S) dS)/|S|^2
+__global__ __launch_bounds__(256) void polar_decompose_bwd_kernel(const cf* __restrict__ spec, const float* __restrict__ gmag,
+                                                                  const float* __restrict__ gphase, cf* __restrict__ gspec, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const cf s = spec[i];
+        const float r = hypotf(s.x, s.y);
+        cf g = mk(0.f, 0.f);
+        if (r > 0.f) {
+            const float ir = 1.0f / r;
+            if (gmag) { const float gm = gmag[i]; g.x += gm * s.x * ir; g.y += gm * s.y * ir; }
+            if (gphase) { const float gp = gphase[i] * ir * ir; g.x += -gp * s.y; g.y += gp * s.x; }
+        }
+        gspec[i] = g;
+    }
+}
+__global__ __launch_bounds__(256) void polar_assemble_kernel(const float* __restrict__ mag, const float* __restrict__ phase,
+                                                             cf* __restrict__ spec, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float sn, cs;
+        sincosf(phase[i], &sn, &cs);
+        const float m = mag[i];
+        spec[i] = mk(m * cs, m * sn);
+    }
+}
+__global__ __launch_bounds__(256) void polar_assemble_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ phase,
+                                                                 const cf* __restrict__ gspec, float* __restrict__ gmag,
+                                                                 float* __restrict__ gphase, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float sn, cs;
+        sincosf(phase[i], &sn, &cs);
+        const cf g = gspec[i];
+        if (gmag) gmag[i] = g.x * cs + g.y * sn;
+        if (gphase) gphase[i] = mag[i] * (g.y * cs - g.x * sn);
+    }
+}
+
+// y = x / m, m = max|x| + 1e-8:  dx_j = g_j / m - [j == k] sign(x_k) (sum_i g_i x_i) / m^2, k = first arg max |x|.
+// One workgroup per clip: max pass, dot pass (f64, fixed order), apply pass.
+__global__ __launch_bounds__(256) void normalize_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                            float* __restrict__ dx, const int* __restrict__ off,
+                                                            const int* __restrict__ len) {
+    __shared__ unsigned long long red[4];
+    __shared__ double dred[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = len[b];
+    const float* xb = x + off[b];
+    const float* gb = g + off[b];
+    float* db = dx + off[b];
+    unsigned long long v = 0;
+    double s = 0.0;
+    for (int i = tid; i < n; i += 256) {
+        const float xv = xb[i];
+        v = umax64(v, pack_max(fabsf(xv), (unsigned)i));
+        s += (double)gb[i] * (double)xv;
+    }
+    v = wave_max64(v);
+    s = wave_sum_d(s);
+    if ((tid & 63) == 0) { red[tid >> 6] = v; dred[tid >> 6] = s; }
+    __syncthreads();
+    v = umax64(umax64(red[0], red[1]), umax64(red[2], red[3]));
+    const double dot = (dred[0] + dred[1]) + (dred[2] + dred[3]);
+    const float m = __uint_as_float((unsigned)(v >> 32)) + 1e-8f;
+    const unsigned k = 0xFFFFFFFFu - (unsigned)(v & 0xFFFFFFFFu);
+    const float xk = n > 0 ? xb[min(k, (unsigned)(n - 1))] : 0.f;
+    const float sk = (xk > 0.f) ? 1.f : ((xk < 0.f) ? -1.f : 0.f);
+    const float corr = sk * (float)(dot / ((double)m * (double)m));
+    for (int i = tid; i < n; i += 256) {
+        float d = gb[i] / m;
+        if ((unsigned)i == k) d -= corr;
+        db[i] = d;
+    }
+}
+
+// torch.optim.NAdam single-tensor step followed by the clamp to [lo, hi]; the same arithmetic as the fused epilogue
+// of the analysis adjoint (nadam_clamp_update in dsp_args.hpp)
+__global__ __launch_bounds__(256) void nadam_clamp_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                          float* __restrict__ m, float* __restrict__ v,
+                                                          const float* __restrict__ lo, const float* __restrict__ hi, size_t n,
+                                                          float c_grad, float c_mom, float inv_bc2, float4 hyp) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float mo = m[i], ve = v[i], pv = p[i];
+        nadam_clamp_update(pv, mo, ve, g[i], lo ? lo[i] : -INFINITY, hi ? hi[i] : INFINITY, c_grad, c_mom, inv_bc2, hyp);
+        m[i] = mo; v[i] = ve; p[i] = pv;
+    }
+}
+
+static inline unsigned gridn(size_t n) {
+    size_t g = (n + 255) / 256;
+    return (unsigned)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
+}
+void launch_polar_decompose(const void* spec, float* mag, float* phase, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(polar_decompose_kernel, dim3(gridn(n)), dim3(256), 0, st, (const cf*)spec, mag, phase, n);
+}
+void launch_polar_decompose_bwd(const void* spec, const float* gmag, const float* gphase, void* gspec, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(polar_decompose_bwd_kernel, dim3(gridn(n)), dim3(256), 0, st, (const cf*)spec, gmag, gphase, (cf*)gspec, n);
+}
+void launch_polar_assemble(const float* mag, const float* phase, void* spec, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(polar_assemble_kernel, dim3(gridn(n)), dim3(256), 0, st, mag, phase, (cf*)spec, n);
+}
+void launch_polar_assemble_bwd(const float* mag, const float* phase, const void* gspec, float* gmag, float* gphase, size_t n,
+                               hipStream_t st) {
+    hipLaunchKernelGGL(polar_assemble_bwd_kernel, dim3(gridn(n)), dim3(256), 0, st, mag, phase, (const cf*)gspec, gmag, gphase, n);
+}
+void launch_normalize_bwd(const float* x, const float* g, float* dx, const int* off, const int* len, int B, hipStream_t st) {
+    hipLaunchKernelGGL(normalize_bwd_kernel, dim3(B), dim3(256), 0, st, x, g, dx, off, len);
+}
+void launch_nadam_clamp(float* p, const float* g, float* m, float* v, const float* lo, const float* hi, size_t n, float c_grad,
+                        float c_mom, float bias_corr2, float beta1, float beta2, float eps, hipStream_t st) {
+    const float4 hyp = make_float4(1.0f - beta1, beta2, 1.0f - beta2, eps);
+    hipLaunchKernelGGL(nadam_clamp_kernel, dim3(gridn(n)), dim3(256), 0, st, p, g, m, v, lo, hi, n, c_grad, c_mom,
+                       1.0f / bias_corr2, hyp);
+}
+
+}  // namespace aware

@@ -74,17 +74,7 @@ class AWAREDetectorNet(BaseDetectorNet):
         Only the embedding band reaches the network (callers zero the rest,
         multibit_embedder.py:104, multibit_detector.py:34-37); the band is taken from the
         default plan (500-4000 Hz at 16 kHz)."""
-        from .. import runtime as rt
-        from ..utils.audio import default_plan
-        plan = default_plan()
-        B, F, T = stft_magnitude.shape
-        lo, hi = plan.band_bins
-        batch = _frames_batch(B, T)
-        mag = torch.zeros((B * T, rt.SPEC_STRIDE), dtype=torch.float32, device="cuda")
-        band = stft_magnitude[:, lo:hi + 1, :].to("cuda", torch.float32)         # [B, nb, T]
-        mag[:, : hi - lo + 1] = band.permute(0, 2, 1).reshape(B * T, -1)
-        out = rt.detector_forward(plan, self.device_weights(plan), batch, mag)
-        return out.unsqueeze(-1)
+        return _DetectorNetFn.apply(stft_magnitude.to("cuda", torch.float32), self)
 
     def get_model_info(self):
         total = int(sum(int(np.prod(p.shape)) for p in self.parameters()))
@@ -94,6 +84,44 @@ class AWAREDetectorNet(BaseDetectorNet):
 
 
 def _frames_batch(B, T):
-    """Batch geometry with exactly T frames per clip (n = 256*(T-1) samples)."""
+    """Batch geometry with exactly T frames per clip (n = 256*(T-1) samples); cached."""
+    from ..utils.audio import get_batch
+    return get_batch([max(256 * (T - 1), 513)] * B)
+
+
+def _band_rows(stft_magnitude, plan):
+    """[B, F, T] -> frame-major band rows [B*T, 256] (layout conversion at the seam)."""
     from .. import runtime as rt
-    return rt.Batch([max(256 * (T - 1), 513)] * B)
+    B, F, T = stft_magnitude.shape
+    lo, hi = plan.band_bins
+    mag = torch.zeros((B * T, rt.SPEC_STRIDE), dtype=torch.float32, device=stft_magnitude.device)
+    mag[:, : hi - lo + 1] = stft_magnitude[:, lo:hi + 1, :].permute(0, 2, 1).reshape(B * T, -1)
+    return mag
+
+
+class _DetectorNetFn(torch.autograd.Function):
+    """AWAREDetectorNet.forward under autograd (the reference back-propagates the loss through the frozen network to the
+    magnitudes, multibit_embedder.py:107-111): forward = aware_detector_forward, backward = aware_detector_backward."""
+
+    @staticmethod
+    def forward(ctx, stft_magnitude, net):
+        from .. import runtime as rt
+        from ..utils.audio import default_plan
+        plan = default_plan()
+        B, F, T = stft_magnitude.shape
+        batch = _frames_batch(B, T)
+        mag = _band_rows(stft_magnitude, plan)
+        ctx.save_for_backward(mag)
+        ctx.geom = (plan, batch, net, (B, F, T))
+        return rt.detector_forward(plan, net.device_weights(plan), batch, mag).unsqueeze(-1)
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import runtime as rt
+        (mag,) = ctx.saved_tensors
+        plan, batch, net, (B, F, T) = ctx.geom
+        _, gmag = rt.detector_backward(plan, net.device_weights(plan), batch, mag, g.reshape(B, -1))
+        lo, hi = plan.band_bins
+        out = torch.zeros((B, F, T), dtype=torch.float32, device=g.device)
+        out[:, lo:hi + 1, :] = gmag[:, : hi - lo + 1].reshape(B, T, -1).permute(0, 2, 1)
+        return out, None

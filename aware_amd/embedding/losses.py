@@ -68,8 +68,22 @@ class BERLoss(_KernelLoss):
         return torch.mean((torch.sign(predicted) != torch.sign(target_pattern)).float())
 
 
+class PushToExtremesL1Loss(_KernelLoss):
+    """EXTENSION (not in the reference; BASELINE.json config 3 "BER + L1 loss"): push_extremes at the read-out plus
+    l1_weight * mean|c - c0| over the clip's in-band coefficients, evaluated inside the embed loop's kernels (the
+    coefficients never leave the device).  forward() here is the read-out part only.  Specified by
+    oracle/aware_oracle.py (Embedder.forward_loss) -- parity unpinned."""
+    kernel_id, name = 6, "push_extremes_l1"
+
+    def __init__(self, l1_weight: float = 0.05):
+        self.l1_weight = float(l1_weight)
+
+    def forward(self, predicted, target_pattern):
+        return torch.mean((predicted - target_pattern) ** 2) - 0.1 * torch.mean(torch.abs(predicted))
+
+
 registry = {"hinge": HingeLoss, "mse": MSELoss, "push_extremes": PushToExtremesLoss, "push_sigmoid": PushToExtremesSigmoidLoss,
-            "sign": SignBasedLoss, "ber": BERLoss}
+            "sign": SignBasedLoss, "ber": BERLoss, "push_extremes_l1": PushToExtremesL1Loss}
 # F.binary_cross_entropy needs predictions in [0, 1]; the detector ends in tanh, so the reference's
 # "bce" entry (losses.py:79-81) raises inside torch for its own model card -- refused here by name
 _NOT_ON_HIP = ("bce",)

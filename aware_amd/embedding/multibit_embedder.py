@@ -64,7 +64,8 @@ class AWAREEmbedder(BaseEmbedder):
         return rt.EmbedSession(plan, self.detection_net.device_weights(plan), batch,
                                num_iterations=self.num_iterations, tolerance_db=self.tolerance_db,
                                loss=self.loss.name, lr=self._opt["lr"], beta1=b1, beta2=b2, eps=self._opt["eps"],
-                               momentum_decay=self._opt["momentum_decay"], use_graph=self.use_graph)
+                               momentum_decay=self._opt["momentum_decay"], use_graph=self.use_graph,
+                               l1_weight=getattr(self.loss, "l1_weight", 0.0))
 
     def embed_device(self, audio: torch.Tensor, batch: "rt.Batch", sample_rate: int, watermarks: torch.Tensor,
                      rescale: torch.Tensor | None = None, session: "rt.EmbedSession" = None):

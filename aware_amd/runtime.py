@@ -16,7 +16,7 @@ from ._lib import AwareHipError, EmbedConfig, check, load_library, require_gpu
 
 SPEC_STRIDE = 256
 FULL_STRIDE = 520
-LOSS_KINDS = {"push_extremes": 0, "mse": 1, "hinge": 2, "sign": 3, "push_sigmoid": 4, "ber": 5}
+LOSS_KINDS = {"push_extremes": 0, "mse": 1, "hinge": 2, "sign": 3, "push_sigmoid": 4, "ber": 5, "push_extremes_l1": 6}
 
 
 def _stream():
@@ -135,6 +135,100 @@ def stft_band(plan: Plan, batch: Batch, audio: torch.Tensor, normalize=True):
     return mag, ph
 
 
+def stft_bwd(plan: Plan, batch: Batch, grad_spec: torch.Tensor) -> torch.Tensor:
+    """Backward of `stft` (normalize=False): grad_spec [total_frames, 520] complex64 -> grad_audio [total_out] f32.
+    Clips must be exactly 256*(T-1) samples long (the iSTFT outputs the reference's loop transforms)."""
+    out = torch.empty(batch.total_out, dtype=torch.float32, device=grad_spec.device)
+    rc = plan.lib.aware_stft_bwd(plan.h, batch.h, _ptr(grad_spec), _ptr(out), _stream())
+    if rc == -2:
+        raise NotImplementedError("stft backward needs clips of exactly hop*(T-1) samples")
+    check(rc, "aware_stft_bwd")
+    return out
+
+
+def istft_bwd(plan: Plan, batch: Batch, grad_audio: torch.Tensor) -> torch.Tensor:
+    """Backward of `istft` (normalize=False): grad_audio [total_out] -> grad_spec [total_frames, 520] complex64."""
+    gs = torch.empty((batch.total_frames, FULL_STRIDE), dtype=torch.complex64, device=grad_audio.device)
+    check(plan.lib.aware_istft_bwd(plan.h, batch.h, _ptr(grad_audio), _ptr(gs), _stream()), "aware_istft_bwd")
+    return gs
+
+
+def polar_decompose(spec: torch.Tensor):
+    lib = load_library()
+    mag = torch.empty(spec.shape, dtype=torch.float32, device=spec.device)
+    ph = torch.empty(spec.shape, dtype=torch.float32, device=spec.device)
+    check(lib.aware_polar_decompose(_ptr(spec), _ptr(mag), _ptr(ph), spec.numel(), _stream()), "aware_polar_decompose")
+    return mag, ph
+
+
+def polar_decompose_bwd(spec, grad_mag, grad_phase):
+    lib = load_library()
+    gs = torch.empty_like(spec)
+    check(lib.aware_polar_decompose_bwd(_ptr(spec), _ptr(grad_mag), _ptr(grad_phase), _ptr(gs), spec.numel(), _stream()),
+          "aware_polar_decompose_bwd")
+    return gs
+
+
+def polar_assemble(mag: torch.Tensor, phase: torch.Tensor) -> torch.Tensor:
+    lib = load_library()
+    spec = torch.empty(mag.shape, dtype=torch.complex64, device=mag.device)
+    check(lib.aware_polar_assemble(_ptr(mag), _ptr(phase), _ptr(spec), mag.numel(), _stream()), "aware_polar_assemble")
+    return spec
+
+
+def polar_assemble_bwd(mag, phase, grad_spec, need_mag=True, need_phase=True):
+    lib = load_library()
+    gm = torch.empty_like(mag) if need_mag else None
+    gp = torch.empty_like(mag) if need_phase else None
+    check(lib.aware_polar_assemble_bwd(_ptr(mag), _ptr(phase), _ptr(grad_spec), _ptr(gm), _ptr(gp), mag.numel(), _stream()),
+          "aware_polar_assemble_bwd")
+    return gm, gp
+
+
+def waveform_normalize_bwd(x: "Ragged", grad_out: torch.Tensor) -> torch.Tensor:
+    lib = load_library()
+    gi = torch.empty_like(x.data)
+    check(lib.aware_waveform_normalize_bwd(_ptr(x.data), _ptr(grad_out), _ptr(gi), _ptr(x.d_off), _ptr(x.d_len), x.B, _stream()),
+          "aware_waveform_normalize_bwd")
+    return gi
+
+
+class NAdamClamp:
+    """torch.optim.NAdam (single tensor, defaults of cards/config.yaml) followed by torch.clamp(param, lo, hi), as ONE
+    kernel on the caller's tensors (aware_nadam_clamp_step): the optimiser step of the reference's loop
+    (embedding/multibit_embedder.py:112-117) for the plug-in seam."""
+
+    def __init__(self, param: torch.Tensor, lr=0.1, betas=(0.9, 0.999), eps=1e-8, momentum_decay=4e-3):
+        self.lib = load_library()
+        self.param = param
+        self.lr, self.betas, self.eps, self.md = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(momentum_decay)
+        self.exp_avg = torch.zeros_like(param)
+        self.exp_avg_sq = torch.zeros_like(param)
+        self.mu_product = C.c_float(1.0)
+        self.t = 0
+
+    def step(self, grad: torch.Tensor, lo: torch.Tensor | None = None, hi: torch.Tensor | None = None):
+        self.t += 1
+        c3 = (C.c_float * 3)()
+        check(self.lib.aware_nadam_coefficients(self.t, self.lr, self.betas[0], self.betas[1], self.md, C.byref(self.mu_product), c3),
+              "aware_nadam_coefficients")
+        check(self.lib.aware_nadam_clamp_step(_ptr(self.param), _ptr(grad), _ptr(self.exp_avg), _ptr(self.exp_avg_sq), _ptr(lo),
+                                              _ptr(hi), self.param.numel(), c3, self.betas[0], self.betas[1], self.eps, _stream()),
+              "aware_nadam_clamp_step")
+
+
+def detector_backward(plan: Plan, det: "DetectorWeights", batch: Batch, mag: torch.Tensor, grad_values: torch.Tensor):
+    """(values [B, n_bits], grad_mag [total_frames, 256]) = forward and J^T grad_values of the frozen network."""
+    nbytes = plan.lib.aware_detector_backward_workspace_bytes(batch.h, det.h)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=mag.device)
+    vals = torch.empty((batch.B, det.n_bits), dtype=torch.float32, device=mag.device)
+    gmag = torch.empty((batch.total_frames, SPEC_STRIDE), dtype=torch.float32, device=mag.device)
+    gv = grad_values.contiguous().float()
+    check(plan.lib.aware_detector_backward(det.h, batch.h, _ptr(mag), _ptr(gv), _ptr(vals), _ptr(gmag), _ptr(ws), nbytes, _stream()),
+          "aware_detector_backward")
+    return vals, gmag
+
+
 class DetectorWeights:
     """Device copy of the frozen detector (aware_detector)."""
 
@@ -189,7 +283,7 @@ class EmbedSession:
 
     def __init__(self, plan: Plan, det: DetectorWeights, batch: Batch, num_iterations=400, tolerance_db=6.0,
                  loss="push_extremes", lr=0.1, beta1=0.9, beta2=0.999, eps=1e-8, momentum_decay=4e-3,
-                 use_graph=True, conv_pipe="bf16x3", fused_readout=True, dsp_path="stream"):
+                 use_graph=True, conv_pipe="bf16x3", fused_readout=True, dsp_path="stream", l1_weight=0.0):
         """conv_pipe: "bf16x3" (default: bf16 matrix pipe, exact three-way operand split) or "f32" (f32-input MFMA);
         fused_readout=False selects the three-kernel read-out that ragged batches use; dsp_path: "stream" (default:
         streaming wave kernels) or "staged" (workgroup-staged kernels) for the STFT / iSTFT stages (aware_embed_config)."""
@@ -201,7 +295,7 @@ class EmbedSession:
             raise ValueError(f"Unknown conv_pipe: {conv_pipe}")
         self.cfg = EmbedConfig(int(num_iterations), float(tolerance_db), LOSS_KINDS[loss], lr, beta1, beta2, eps,
                                momentum_decay, int(bool(use_graph)), 0 if conv_pipe == "bf16x3" else 1,
-                               0 if fused_readout else 1, {"stream": 0, "staged": 1}[dsp_path])
+                               0 if fused_readout else 1, {"stream": 0, "staged": 1}[dsp_path], float(l1_weight))
         self.nbytes = self.lib.aware_embed_workspace_bytes(batch.h, det.h)
         self.ws = torch.empty(self.nbytes, dtype=torch.uint8, device=_dev())
         h = C.c_void_p()

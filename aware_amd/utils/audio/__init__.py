@@ -1,5 +1,5 @@
 from .plugins import (STFT, ISTFT, STFTDecomposer, STFTAssembler, STFTNormalizer, WaveformNormalizer,
-                      SilenceChecker, band_bins, get_plan, default_plan)
+                      SilenceChecker, band_bins, get_plan, default_plan, get_batch)
 
 __all__ = ["STFT", "STFTDecomposer", "STFTAssembler", "ISTFT", "WaveformNormalizer", "SilenceChecker",
-           "STFTNormalizer", "band_bins", "get_plan", "default_plan"]
+           "STFTNormalizer", "band_bins", "get_plan", "default_plan", "get_batch"]

@@ -41,61 +41,148 @@ def _as_device(x: torch.Tensor) -> torch.Tensor:
     return x.to("cuda", torch.float32).contiguous()
 
 
-class WaveformNormalizer(BaseAudioProcessor):
-    """x / max(|x| + 1e-8) over the whole tensor (waveform.py:18-19)."""
-
-    def __call__(self, data: torch.Tensor) -> torch.Tensor:
-        x = _as_device(data).reshape(-1)
-        out = rt.waveform_normalize(rt.Ragged(x, [x.numel()]))
-        return out.data.reshape(data.shape)
+_BATCHES = {}
 
 
-class STFT(BaseAudioProcessor):
-    """torch.stft(center=True, window, return_complex=True) (stft.py:14-28)."""
+def get_batch(lengths) -> "rt.Batch":
+    """Geometry handles are cached per (device, lengths): a plug-in call does no hipMalloc / host-to-device table copy
+    after its first use of a shape."""
+    key = (torch.cuda.current_device(),) + tuple(int(n) for n in lengths)
+    if key not in _BATCHES:
+        if len(_BATCHES) > 256:
+            _BATCHES.clear()
+        _BATCHES[key] = rt.Batch(list(key[1:]))
+    return _BATCHES[key]
 
-    def __init__(self, n_fft: int = 2048, hop_length: int = 512, window: str = "hann", win_length: int = 2048):
-        if window not in ("hann", "hamming"):
-            raise ValueError(f"Invalid window type: {window}")
-        self.n_fft, self.hop_length, self.window_name, self.win_length = n_fft, hop_length, window, win_length
 
-    def __call__(self, data: torch.Tensor) -> torch.Tensor:
-        x = _as_device(data)
-        plan = get_plan(self.n_fft, self.hop_length, self.window_name)
-        batch = rt.Batch([x.numel()])
+# ---- differentiable forms: torch.autograd.Function wrappers whose forward and backward are C-ABI calls ----------
+# (the reference's loop differentiates through these objects with autograd, multibit_embedder.py:49-67,:111)
+class _NormalizeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        flat = x.reshape(-1)
+        rg = rt.Ragged(flat, [flat.numel()])
+        ctx.save_for_backward(flat)
+        return rt.waveform_normalize(rg).data.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        (flat,) = ctx.saved_tensors
+        rg = rt.Ragged(flat, [flat.numel()])
+        return rt.waveform_normalize_bwd(rg, g.contiguous().reshape(-1).float()).reshape(g.shape)
+
+
+class _STFTFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, n_fft, hop, window):
+        plan = get_plan(n_fft, hop, window)
+        batch = get_batch([x.numel()])
+        ctx.geom = (plan, batch, n_fft)
         spec = rt.stft(plan, batch, x, normalize=False)
-        return spec[:, : self.n_fft // 2 + 1].transpose(0, 1).contiguous()        # [F, T]
+        return spec[:, : n_fft // 2 + 1].transpose(0, 1).contiguous()        # [F, T]
+
+    @staticmethod
+    def backward(ctx, g):
+        plan, batch, n_fft = ctx.geom
+        F = n_fft // 2 + 1
+        gs = torch.zeros((batch.total_frames, rt.FULL_STRIDE), dtype=torch.complex64, device=g.device)
+        gs[:, :F] = g.transpose(0, 1)
+        return rt.stft_bwd(plan, batch, gs), None, None, None
 
 
-class ISTFT(BaseAudioProcessor):
-    """torch.istft(center=True, window) without `length` (stft.py:34-48)."""
-
-    def __init__(self, n_fft: int = 2048, hop_length: int = 512, window: str = "hann", win_length: int = 2048):
-        if window not in ("hann", "hamming"):
-            raise ValueError(f"Invalid window type: {window}")
-        self.n_fft, self.hop_length, self.window_name, self.win_length = n_fft, hop_length, window, win_length
-
-    def __call__(self, data: torch.Tensor) -> torch.Tensor:
-        X = data.to("cuda", torch.complex64)
+class _ISTFTFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, n_fft, hop, window):
         F, T = X.shape
-        plan = get_plan(self.n_fft, self.hop_length, self.window_name)
-        batch = rt.Batch([max(self.hop_length * (T - 1), self.n_fft // 2 + 1)])
-        spec = torch.zeros((T, rt.FULL_STRIDE), dtype=torch.complex64, device="cuda")
+        plan = get_plan(n_fft, hop, window)
+        batch = get_batch([max(hop * (T - 1), n_fft // 2 + 1)])
+        ctx.geom = (plan, batch, F)
+        spec = torch.zeros((T, rt.FULL_STRIDE), dtype=torch.complex64, device=X.device)
         spec[:, :F] = X.transpose(0, 1)
         return rt.istft(plan, batch, spec, normalize=False)
 
+    @staticmethod
+    def backward(ctx, g):
+        plan, batch, F = ctx.geom
+        gs = rt.istft_bwd(plan, batch, g.contiguous().float())
+        return gs[:, :F].transpose(0, 1).contiguous(), None, None, None
+
+
+class _DecomposeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, S):
+        S = S.contiguous()
+        ctx.save_for_backward(S)
+        return rt.polar_decompose(S)
+
+    @staticmethod
+    def backward(ctx, gmag, gphase):
+        (S,) = ctx.saved_tensors
+        gm = None if gmag is None else gmag.contiguous().float()
+        gp = None if gphase is None else gphase.contiguous().float()
+        if gm is None and gp is None:
+            return torch.zeros_like(S)
+        return rt.polar_decompose_bwd(S, gm, gp)
+
+
+class _AssembleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mag, phase):
+        mag, phase = mag.contiguous().float(), phase.contiguous().float()
+        ctx.save_for_backward(mag, phase)
+        return rt.polar_assemble(mag, phase)
+
+    @staticmethod
+    def backward(ctx, g):
+        mag, phase = ctx.saved_tensors
+        gm, gp = rt.polar_assemble_bwd(mag, phase, g.contiguous(), ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return gm, gp
+
+
+class WaveformNormalizer(BaseAudioProcessor):
+    """x / max(|x| + 1e-8) over the whole tensor (waveform.py:18-19); differentiable (through the max, as autograd does)."""
+
+    def __call__(self, data: torch.Tensor) -> torch.Tensor:
+        return _NormalizeFn.apply(_as_device(data))
+
+
+class STFT(BaseAudioProcessor):
+    """torch.stft(center=True, window, return_complex=True) (stft.py:14-28); differentiable for inputs of hop*(T-1)
+    samples (the iSTFT outputs the reference's loop feeds it)."""
+
+    def __init__(self, n_fft: int = 2048, hop_length: int = 512, window: str = "hann", win_length: int = 2048):
+        if window not in ("hann", "hamming"):
+            raise ValueError(f"Invalid window type: {window}")
+        self.n_fft, self.hop_length, self.window_name, self.win_length = n_fft, hop_length, window, win_length
+
+    def __call__(self, data: torch.Tensor) -> torch.Tensor:
+        return _STFTFn.apply(_as_device(data), self.n_fft, self.hop_length, self.window_name)
+
+
+class ISTFT(BaseAudioProcessor):
+    """torch.istft(center=True, window) without `length` (stft.py:34-48); differentiable."""
+
+    def __init__(self, n_fft: int = 2048, hop_length: int = 512, window: str = "hann", win_length: int = 2048):
+        if window not in ("hann", "hamming"):
+            raise ValueError(f"Invalid window type: {window}")
+        self.n_fft, self.hop_length, self.window_name, self.win_length = n_fft, hop_length, window, win_length
+
+    def __call__(self, data: torch.Tensor) -> torch.Tensor:
+        return _ISTFTFn.apply(data.to("cuda", torch.complex64), self.n_fft, self.hop_length, self.window_name)
+
 
 class STFTDecomposer(BaseAudioProcessor):
-    """(|S|, angle S) (stft.py:54-55)."""
+    """(|S|, angle S) (stft.py:54-55); differentiable (d|S| = 0 at S = 0, torch's convention)."""
 
     def __call__(self, data: torch.Tensor):
-        return torch.abs(data), torch.angle(data)
+        return _DecomposeFn.apply(data.to("cuda", torch.complex64))
 
 
 class STFTAssembler(BaseAudioProcessor):
-    """mag * exp(i phase) (stft.py:61-62)."""
+    """mag * exp(i phase) (stft.py:61-62); differentiable."""
 
     def __call__(self, magnitude: torch.Tensor, phase: torch.Tensor) -> torch.Tensor:
-        return torch.polar(magnitude.float(), phase.float())
+        return _AssembleFn.apply(magnitude.to("cuda"), phase.to("cuda"))
 
 
 class STFTNormalizer(BaseAudioProcessor):

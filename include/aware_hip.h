@@ -37,6 +37,16 @@ extern "C" {
 #define AWARE_E_HIP (-3)           /* a HIP runtime call failed; see aware_last_hip_error() */
 #define AWARE_E_WORKSPACE (-4)     /* caller's workspace too small */
 
+/* loss kinds (embedding/losses.py:95-103 and two additions) */
+#define AWARE_LOSS_PUSH_EXTREMES 0
+#define AWARE_LOSS_MSE 1
+#define AWARE_LOSS_HINGE 2
+#define AWARE_LOSS_SIGN 3
+#define AWARE_LOSS_PUSH_SIGMOID 4
+#define AWARE_LOSS_BER 5            /* no gradient, losses.py:90-92 */
+#define AWARE_LOSS_PUSH_L1 6        /* EXTENSION (BASELINE config 3 "BER+L1"): push_extremes + l1_weight * mean|c - c0| */
+#define AWARE_LOSS_EXTERNAL 7       /* internal: `target` holds dL/dpred (aware_detector_backward) */
+
 #define AWARE_SPEC_STRIDE 256      /* floats per frame row of a band-limited array */
 #define AWARE_FULL_STRIDE 520      /* complex values per frame row of a full one-sided spectrum */
 
@@ -91,6 +101,41 @@ int aware_istft(const aware_plan* plan, const aware_batch* batch, const void* sp
 int aware_stft_band(const aware_plan* plan, const aware_batch* batch, const float* audio, int normalize,
                     float* mag, void* phasor, void* scratch, void* stream);
 
+/* Backward passes of the two transforms for the differentiable plug-in seam (BaseAudioProcessor.__call__,
+ * interfaces/audio.py:6-9; what torch autograd derives for torch.stft / torch.istft inside
+ * embedding/multibit_embedder.py:49-67).  Gradients of a real loss; complex gradients in torch's convention
+ * (dL/dRe + i dL/dIm).
+ * aware_stft_bwd: grad_spec dev complex64 [total frames][AWARE_FULL_STRIDE] -> grad_audio dev f32 (clip b at
+ *   aware_batch_out_offset).  Implemented for clips of exactly 256*(T-1) samples, densely packed (the iSTFT output the
+ *   reference's loop transforms); AWARE_E_UNSUPPORTED otherwise.
+ * aware_istft_bwd: grad_audio dev f32 [total out] -> grad_spec dev complex64 [total frames][AWARE_FULL_STRIDE]. */
+int aware_stft_bwd(const aware_plan* plan, const aware_batch* batch, const void* grad_spec, float* grad_audio,
+                   void* stream);
+int aware_istft_bwd(const aware_plan* plan, const aware_batch* batch, const float* grad_audio, void* grad_spec,
+                    void* stream);
+
+/* The element-wise plug-ins and the optimiser step of the reference's loop, with their backward passes, for the same
+ * seam (n = number of complex / real elements; all pointers dev):
+ *   aware_polar_decompose      STFTDecomposer: (|S|, angle S)  utils/audio/stft.py:54-55  (phase may be NULL)
+ *   aware_polar_assemble       STFTAssembler: mag * exp(i phase)  utils/audio/stft.py:61-62
+ *   aware_waveform_normalize_bwd  backward of x / max(|x| + 1e-8), utils/audio/waveform.py:18-19 (through the max)
+ *   aware_nadam_clamp_step     torch.optim.NAdam single-tensor step + torch.clamp(coeffs, lo, hi)
+ *                              (embedding/multibit_embedder.py:112-117); coef3 = the three per-step scalars written by
+ *                              aware_nadam_coefficients (host; mu_product_io carries torch's mu_product between steps,
+ *                              start it at 1.0f; step counts from 1).  Same arithmetic as the fused loop. */
+int aware_polar_decompose(const void* spec, float* mag, float* phase, size_t n, void* stream);
+int aware_polar_decompose_bwd(const void* spec, const float* grad_mag, const float* grad_phase, void* grad_spec, size_t n,
+                              void* stream);
+int aware_polar_assemble(const float* mag, const float* phase, void* spec, size_t n, void* stream);
+int aware_polar_assemble_bwd(const float* mag, const float* phase, const void* grad_spec, float* grad_mag,
+                             float* grad_phase, size_t n, void* stream);
+int aware_waveform_normalize_bwd(const float* in, const float* grad_out, float* grad_in, const int* off, const int* len,
+                                 int B, void* stream);
+int aware_nadam_coefficients(int step, float lr, float beta1, float beta2, float momentum_decay, float* mu_product_io,
+                             float* coef3);
+int aware_nadam_clamp_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* lo,
+                           const float* hi, size_t n, const float* coef3, float beta1, float beta2, float eps, void* stream);
+
 /* ---- detector --------------------------------------------------------------------------------
  * AWAREDetectorNet (detection/multibit_detector_net.py:17-80).  All arrays are host fp32:
  * mel_basis [n_mels][n_fft/2+1] (detection/modules/mel.py:105-149), conv weights
@@ -111,10 +156,19 @@ int aware_detect(const aware_plan* plan, const aware_detector* det, const aware_
 int aware_detector_forward(const aware_detector* det, const aware_batch* batch, const float* mag,
                            float* values, void* workspace, size_t workspace_bytes, void* stream);
 
+/* forward + backward of the network for the differentiable seam (BaseDetectorNet.forward, interfaces/detection.py:10-14,
+ * under autograd): values [B][n_bits] (may be NULL) and grad_mag [total frames][256] = J^T grad_values; data gradients
+ * only (the reference freezes the weights, multibit_embedder.py:76-77). */
+size_t aware_detector_backward_workspace_bytes(const aware_batch* batch, const aware_detector* det);
+int aware_detector_backward(const aware_detector* det, const aware_batch* batch, const float* mag,
+                            const float* grad_values, float* values, float* grad_mag, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
 /* ---- embedder -----------------------------------------------------------------------------------
  * AWAREEmbedder.embed / _optimize (embedding/multibit_embedder.py:70-197), batched and ragged:
- * every clip is its own optimisation problem.  loss: 0 push_extremes, 1 mse, 2 hinge, 3 sign,
- * 4 push_sigmoid, 5 ber (no gradient) (embedding/losses.py:95-103; bce needs sigmoid outputs).  optimizer: NAdam (embedding/optimizers.py:5; torch.optim.NAdam
+ * every clip is its own optimisation problem.  loss: AWARE_LOSS_* above -- 0 push_extremes, 1 mse, 2 hinge, 3 sign,
+ * 4 push_sigmoid, 5 ber (no gradient) (embedding/losses.py:95-103; bce needs sigmoid outputs), 6 push_extremes + L1
+ * (EXTENSION, streaming DSP path only).  optimizer: NAdam (embedding/optimizers.py:5; torch.optim.NAdam
  * single-tensor semantics) with lr, beta1, beta2, eps, momentum_decay; the reference's
  * ReduceLROnPlateau(patience 500) never fires within 400 iterations and is not modelled. */
 typedef struct aware_embed_config {
@@ -137,6 +191,9 @@ typedef struct aware_embed_config {
      *   bins 1..256; 1: workgroup-staged kernels (csrc/dsp_kernels.hip: any band; the form the streaming kernels are
      *   tested against). */
     int dsp_path;
+    /* loss AWARE_LOSS_PUSH_L1 only (EXTENSION, BASELINE config 3 "BER + L1"; the reference's imperceptibility device is
+     * the box constraint :157-160, which stays in force): weight of mean|c - c0| over a clip's 225*T coefficients */
+    float l1_weight;
 } aware_embed_config;
 
 size_t aware_embed_workspace_bytes(const aware_batch* batch, const aware_detector* det);

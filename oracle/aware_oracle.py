@@ -237,6 +237,10 @@ LOSSES = {
     "sign": lambda p, t: torch.clamp(-p * t, min=0).mean(dim=-1),
     "push_sigmoid": lambda p, t: ((p - t) ** 2).mean(dim=-1) - 0.1 * (p - 0.5).abs().mean(dim=-1),
     "ber": lambda p, t: (torch.sign(p) != torch.sign(t)).float().mean(dim=-1) + 0.0 * p.sum(dim=-1),
+    # EXTENSION (not in the reference; BASELINE.json config 3 "BER + L1 loss"): the read-out part is push_extremes,
+    # Embedder.forward_loss adds l1_weight * mean|c - c0| over the clip's coefficients.  Parity unpinned: this
+    # restatement IS the specification of loss id 6 (AWARE_LOSS_PUSH_L1).
+    "push_extremes_l1": push_extremes_loss,
 }
 
 
@@ -277,8 +281,9 @@ class Embedder:
     """AWAREEmbedder.embed / _optimize -- embedding/multibit_embedder.py:70-197."""
 
     def __init__(self, num_iterations=NUM_ITERATIONS, tolerance_db=TOLERANCE_DB,
-                 loss="push_extremes", dtype=torch.float32):
+                 loss="push_extremes", dtype=torch.float32, l1_weight=0.0):
         self.det = Detector(dtype)
+        self.l1_weight = l1_weight if loss == "push_extremes_l1" else 0.0
         self.num_iterations = num_iterations
         self.tolerance_db = tolerance_db
         self.loss = LOSSES[loss]
@@ -316,7 +321,11 @@ class Embedder:
         mag2 = mag2.clone()
         mag2[:, self.nonband] = 0.0
         pred = self.det.forward(mag2)
-        return self.loss(pred, target), pred
+        loss = self.loss(pred, target)
+        if self.l1_weight:
+            # EXTENSION: imperceptibility as an L1 penalty on the coefficient change, per clip
+            loss = loss + self.l1_weight * (coeffs - mag0[:, self.band]).abs().mean(dim=(-2, -1))
+        return loss, pred
 
     def embed(self, audio, watermark, record=None):
         """embed (:141-197).  audio [B, n] f32, watermark [B, 20] bipolar.

@@ -411,7 +411,7 @@ def test_fused_path_on_another_detector_geometry(rt, plan, O):
 
 # ---------------------------------------------------------------------------------------------------------
 # round 2: the tolerance box, the 3 s golden trajectory and the 44.1 kHz golden on the HIP path
-# (tolerances = 3x the drift measured on MI355X by tools/measure_drift.py, recorded in profiles/r02_drift.json)
+# (tolerances = 3x the drift measured on MI355X by tests/tools/measure_drift.py, recorded in profiles/r02_drift.json)
 # ---------------------------------------------------------------------------------------------------------
 # Measured on MI355X against the reference's recorded run (profiles/r02_drift.json; worst of the 1 s and 3 s golden
 # clips; the f32-MFMA pipe drifts by the same amounts, 5.8e-3 / 3.7e-3 max): |loss - reference loss| is 0 at step 0,
@@ -570,7 +570,7 @@ def test_stream_vs_staged_dsp_kernels(rt, plan, det, O, lengths):
         rel = ((g1[sl] - g0[sl]).norm() / g0[sl].norm()).item()
         print(f"clip {i} (n = {lengths[i]}): stream vs staged gradient rel L2 {rel:.2e}")
         # clips of a few frames have 2-3 pooled frames per channel: the InstanceNorm of two nearly equal values is
-        # ill-conditioned (both forms are 1e-3..1e-2 from the float64 oracle there, tools/small_clip_check.py)
+        # ill-conditioned (both forms are 1e-3..1e-2 from the float64 oracle there, tests/tools/small_clip_check.py)
         assert rel < (2e-4 if batch.frames[i] >= 8 else 5e-2), (i, rel)
     assert np.max(np.abs(lb1 - lb0)) < 2e-3
     assert float((o1 - o0).abs().max()) < 2e-2        # three NAdam steps of lr 0.1 amplify rounding differences
