@@ -561,6 +561,12 @@ static int det_forward(const aware_detector* d, const aware_batch* b, const floa
                                  nullptr, st);
                 LAUNCHCHK(); PROF(K_GEMM_CLIP_FWD);
             }
+        } else if (!nwm && pipe == 0 && co >= 128 && d->wpk[l] && gemm_clip_x3_supported(1, co, ci, ci)) {
+            // ragged batch / clips longer than the uniform kernel's tile: conv + InstanceNorm + LeakyReLU in one launch,
+            // clips walked in chunks of rows (gemm_ragged_x3_kernel)
+            launch_gemm_ragged_x3(x, ci, d->wpk[l], d->bias[l], o.act[l], co, b->B, b->d_frame_off, b->d_pool_off, co, ci, 1,
+                                  o.rstd[l], nullptr, st);
+            LAUNCHCHK(); PROF(K_GEMM_X3_FWD);
         } else {
             gemm_plain(pipe, x, ci, d->w[l], ci, d->wpk[l], d->bias[l], o.act[l], co, b->NP, co, ci, st);
             LAUNCHCHK(); PROF(K_GEMM);
@@ -685,6 +691,12 @@ static int det_forward_backward(const aware_detector* d, const aware_batch* b, c
                                  db.act[l - 1], st);
                 LAUNCHCHK(); PROF(K_GEMM_CLIP_BWD);
             }
+        } else if (!nwm && pipe == 0 && l > 0 && ci >= 128 && d->wTpk[l] && gemm_clip_x3_supported(1, ci, co, co)) {
+            // ragged batch: data-gradient GEMM + backward of block l-1's InstanceNorm + LeakyReLU in one launch
+            dz_ready = true;
+            launch_gemm_ragged_x3(dA, co, d->wTpk[l], nullptr, dB, ci, b->B, b->d_frame_off, b->d_pool_off, ci, co, 2,
+                                  db.rstd[l - 1], db.act[l - 1], st);
+            LAUNCHCHK(); PROF(K_GEMM_X3_BWD);
         } else {
             gemm_plain(pipe, dA, co, d->wT[l], co, d->wTpk[l], nullptr, dB, ci, b->NP, ci, co, st);
             dz_ready = false;

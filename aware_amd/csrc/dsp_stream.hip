@@ -70,7 +70,8 @@ __device__ __forceinline__ float env_at(const PlanDev& pl, int p, int T) {
 // ---------------------------------------------------------------------------------------------------------
 // Analysis: a wave transforms frames t0 .. t0 + nfr - 1 of one clip
 // ---------------------------------------------------------------------------------------------------------
-template <int MODE>
+// L1: the push_extremes + L1 objective (EXTENSION) adds l1_weight * sign(c - c0) / (nband T) to the gradient
+template <int MODE, bool L1>
 __global__ __launch_bounds__(kSThreads, MODE == AN_ADJ ? 3 : 4) void analysis_stream_kernel(AnalysisArgs a, int run_frames) {
     __shared__ cf tw1s[512];
     __shared__ cf tw2s[64];
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(kSThreads, MODE == AN_ADJ ? 3 : 4) void analysis_st
         improved = a.improved[b];
     }
 
-    const float l1g = (MODE == AN_ADJ && a.c0) ? a.l1_weight / (float)(nband * T) : 0.f;
+    const float l1g = (MODE == AN_ADJ && L1) ? a.l1_weight / (float)(nband * T) : 0.f;
     float2 raw[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) raw[r] = load_half(kHop * t0 + 128 * r);
@@ -203,8 +204,8 @@ __global__ __launch_bounds__(kSThreads, MODE == AN_ADJ ? 3 : 4) void analysis_st
                 const size_t idx = row * kFS + (size_t)min(max(f, 0), kFS - 1);       // clamped, masked at use
                 preP[r] = a.phasor[idx];
                 if (a.do_step) { preM[r] = a.mom[idx]; preV[r] = a.vel[idx]; preC[r] = a.coef[idx]; preL[r] = a.lo[idx]; preH[r] = a.hi[idx]; }
-                else { preM[r] = preV[r] = preL[r] = preH[r] = 0.f; preC[r] = a.c0 ? a.coef[idx] : 0.f; }
-                pre0[r] = a.c0 ? a.c0[idx] : 0.f;
+                else { preM[r] = preV[r] = preL[r] = preH[r] = 0.f; preC[r] = L1 ? a.coef[idx] : 0.f; }
+                pre0[r] = L1 ? a.c0[idx] : 0.f;
             }
         }
         cf v[8];
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(kSThreads, MODE == AN_ADJ ? 3 : 4) void analysis_st
                 // dL/dc = Re(G conj P) with G = (2/N) rfft(.)  [adjoint of irfft on interior bins]
                 const cf P = preP[r];
                 float g = (X.x * P.x + X.y * P.y) * (1.0f / 512.0f);
-                if (a.c0) {
+                if (L1) {
                     // EXTENSION: + l1_weight * d/dc mean|c - c0| (mean over the clip's nband * T variables; sign(0) = 0)
                     const float dc = preC[r] - pre0[r];
                     g += l1g * ((dc > 0.f) ? 1.f : ((dc < 0.f) ? -1.f : 0.f));
@@ -279,7 +280,8 @@ __global__ __launch_bounds__(kSThreads, MODE == AN_ADJ ? 3 : 4) void analysis_st
 // ---------------------------------------------------------------------------------------------------------
 // Synthesis: a wave produces the hop blocks [jb0, jb1) of one clip from frames jb0-1 .. jb1+1
 // ---------------------------------------------------------------------------------------------------------
-template <int MODE>
+// L1 (SY_FWD only): also emit the per-run sums of |amp - c0| for the loss value of the push_extremes + L1 objective
+template <int MODE, bool L1>
 __global__ __launch_bounds__(kSThreads, 4) void synth_stream_kernel(SynthArgs a) {
     __shared__ cf tw1s[512];
     __shared__ cf tw2s[64];
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(kSThreads, 4) void synth_stream_kernel(SynthArgs a)
         }
         float2 c[8];
         if (t <= T - 1) {
-            if (MODE == SY_FWD && a.pl1 && ((t >= jb0 && t < jb1) || (last && t == T - 1))) {
+            if (MODE == SY_FWD && L1 && ((t >= jb0 && t < jb1) || (last && t == T - 1))) {
                 // own bins of the slots: k = lane + 64 r <= 256 (r < 4, and lane 0 of r = 4)
                 const float* C0 = a.c0 + (size_t)(f0 + t) * kFS;
 #pragma unroll
@@ -466,7 +468,7 @@ __global__ __launch_bounds__(kSThreads, 4) void synth_stream_kernel(SynthArgs a)
             best = wave_max64(best);
             if (lane == 0) a.pmax[(size_t)b * a.pstride + run] = best;
         }
-        if (a.pl1) {
+        if (L1) {
             const double tot = wave_sum_d((double)l1);
             if (lane == 0) a.pl1[(size_t)b * a.pstride + run] = tot;
         }
@@ -518,8 +520,9 @@ void launch_analysis_stream(const AnalysisLaunch& L, hipStream_t st) {
     }
     const int runs = (L.max_frames + R - 1) / R;
     const dim3 grid((unsigned)((runs + kSW - 1) / kSW), (unsigned)L.B, 1);
-    if (L.adjoint) hipLaunchKernelGGL((analysis_stream_kernel<AN_ADJ>), grid, dim3(kSThreads), 0, st, a, R);
-    else hipLaunchKernelGGL((analysis_stream_kernel<AN_NORM>), grid, dim3(kSThreads), 0, st, a, R);
+    if (L.adjoint && a.c0) hipLaunchKernelGGL((analysis_stream_kernel<AN_ADJ, true>), grid, dim3(kSThreads), 0, st, a, R);
+    else if (L.adjoint) hipLaunchKernelGGL((analysis_stream_kernel<AN_ADJ, false>), grid, dim3(kSThreads), 0, st, a, R);
+    else hipLaunchKernelGGL((analysis_stream_kernel<AN_NORM, false>), grid, dim3(kSThreads), 0, st, a, R);
 }
 
 void launch_synth_stream(const SynthLaunch& L, hipStream_t st) {
@@ -535,8 +538,9 @@ void launch_synth_stream(const SynthLaunch& L, hipStream_t st) {
     int runs = (nblk + a.run_blocks - 1) / a.run_blocks;
     if (runs < 1) runs = 1;
     const dim3 grid((unsigned)((runs + kSW - 1) / kSW), (unsigned)L.B, 1);
-    if (L.adjoint) hipLaunchKernelGGL((synth_stream_kernel<SY_ADJ>), grid, dim3(kSThreads), 0, st, a);
-    else hipLaunchKernelGGL((synth_stream_kernel<SY_FWD>), grid, dim3(kSThreads), 0, st, a);
+    if (L.adjoint) hipLaunchKernelGGL((synth_stream_kernel<SY_ADJ, false>), grid, dim3(kSThreads), 0, st, a);
+    else if (a.pl1) hipLaunchKernelGGL((synth_stream_kernel<SY_FWD, true>), grid, dim3(kSThreads), 0, st, a);
+    else hipLaunchKernelGGL((synth_stream_kernel<SY_FWD, false>), grid, dim3(kSThreads), 0, st, a);
 }
 
 }  // namespace aware

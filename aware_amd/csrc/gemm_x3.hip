@@ -97,14 +97,14 @@ void x3_pack(const float* Wt, int N, int K, uint16_t* out) {
                 }
 }
 
-template <int RG, int EPI, int NW>
-__global__ __launch_bounds__(64 * NW) void gemm_clip_x3_kernel(const float* __restrict__ A, int lda,
-                                                                 const u32x4* __restrict__ Bpk, const float* __restrict__ bias,
-                                                                 float* __restrict__ C, int ldc, int Tp, int N, int K,
-                                                                 int tiles_n, int ntiles, float* __restrict__ rstd_io,
-                                                                 const float* __restrict__ act,
-                                                                 const u32x4* __restrict__ Lpk, float* __restrict__ zpart,
-                                                                 int CL) {
+// The K loop of one tile: acc[m][n] += A[bm + 16 m .. +16)[0..K) * B^T for the wave's 16*NTW columns starting at
+// bn + wave*16*NTW.  `lds` is the workgroup's staging memory (2 * 2 * 3 * 2RG KiB); every wave of the workgroup calls this
+// with the same arguments.  The caller provides a barrier between two calls that reuse `lds`.
+// row_limit: rows of A that may be read from bm on (rows beyond it are read from the last permitted row; their products
+// land in accumulator rows the caller does not store).
+template <int RG, int NW>
+__device__ __forceinline__ void x3_tile_gemm(const float* __restrict__ A, int lda, const u32x4* __restrict__ Bpk, int K, int bm,
+                                             int bn, unsigned char* lds, f32x4 (&acc)[2 * RG][8 / NW], int row_limit) {
     constexpr int NT = 64 * NW;
     constexpr int NTW = 8 / NW;           // 16-column tiles per wave (slab = 128 columns)
     constexpr int MT = 2 * RG;            // 16-row tiles per clip
@@ -114,13 +114,6 @@ __global__ __launch_bounds__(64 * NW) void gemm_clip_x3_kernel(const float* __re
     constexpr int KSS = 3 * PLANE;        // one K32 step
     constexpr int BUF = 2 * KSS;          // one K tile (BK = 64)
     constexpr int NCH = (RG * 256 + NT - 1) / NT;     // 8-float chunks of the A tile per thread
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
-
-    int id = blockIdx.x;
-    if ((ntiles & 7) == 0) id = (id & 7) * (ntiles >> 3) + (id >> 3);
-    const int clip = id / tiles_n;
-    const int bm = clip * 32 * RG;
-    const int bn = (id % tiles_n) * 128;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kg = lane >> 4;
@@ -132,9 +125,11 @@ __global__ __launch_bounds__(64 * NW) void gemm_clip_x3_kernel(const float* __re
     const int KS2 = K >> 5;
     const int nkt = K >> 6;
     const u32x4* bp = Bpk + ((size_t)((bn >> 4) + wave * NTW) * KS2) * 192 + lane;
-    const float* ap = A + (size_t)(bm + srow) * lda + sc * 8;
+    const float* ap = A + (size_t)bm * lda + sc * 8;
+    int roff[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) roff[i] = min(srow + (NT / 8) * i, row_limit - 1) * lda;
 
-    f32x4 acc[MT][NTW];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -144,7 +139,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_clip_x3_kernel(const float* __re
     auto chunk_ok = [&](int i) { return (RG * 256) % NT == 0 || tid + NT * i < RG * 256; };
     auto gload_c = [&](int i, int kt) {
         if (chunk_ok(i)) {
-            const float* p = ap + (size_t)((NT / 8) * i) * lda + kt * 64;
+            const float* p = ap + roff[i] + kt * 64;
             ra[i][0] = *reinterpret_cast<const float4*>(p);
             ra[i][1] = *reinterpret_cast<const float4*>(p + 4);
         }
@@ -222,6 +217,35 @@ __global__ __launch_bounds__(64 * NW) void gemm_clip_x3_kernel(const float* __re
             }
         }
     }
+}
+
+// (RG <= 3: two 8-wave workgroups per CU = four waves per SIMD need <= 128 VGPRs; RG = 4 does not fit that)
+template <int RG, int EPI, int NW>
+__global__ __launch_bounds__(64 * NW, (RG <= 3 && NW == 8) ? 4 : 2) void gemm_clip_x3_kernel(const float* __restrict__ A, int lda,
+                                                                 const u32x4* __restrict__ Bpk, const float* __restrict__ bias,
+                                                                 float* __restrict__ C, int ldc, int Tp, int N, int K,
+                                                                 int tiles_n, int ntiles, float* __restrict__ rstd_io,
+                                                                 const float* __restrict__ act,
+                                                                 const u32x4* __restrict__ Lpk, float* __restrict__ zpart,
+                                                                 int CL) {
+    constexpr int NTW = 8 / NW;           // 16-column tiles per wave (slab = 128 columns)
+    constexpr int MT = 2 * RG;            // 16-row tiles per clip
+    constexpr int MH = RG;
+    constexpr int FRAG = 1024;
+    constexpr int BUF = 2 * 3 * MT * FRAG;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
+
+    int id = blockIdx.x;
+    if ((ntiles & 7) == 0) id = (id & 7) * (ntiles >> 3) + (id >> 3);
+    const int clip = id / tiles_n;
+    const int bm = clip * 32 * RG;
+    const int bn = (id % tiles_n) * 128;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kg = lane >> 4;
+
+    f32x4 acc[MT][NTW];
+    x3_tile_gemm<RG, NW>(A, lda, Bpk, K, bm, bn, lds, acc, 32 * RG);
 
     // ---- epilogue: lane holds rows m*16 + 4*kg + e (e = 0..3) of columns cb + n*16 + r16 ----
     const int cb = bn + wave * (16 * NTW) + r16;
@@ -382,6 +406,235 @@ __global__ __launch_bounds__(64 * NW) void gemm_clip_x3_kernel(const float* __re
                 }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Ragged batches: the same conv block (or data-gradient GEMM) for clips of ANY length in ONE launch.
+// A workgroup owns one clip x 128 columns, as above, but takes the clip's rows from the batch tables (pool_off is
+// 32-aligned per clip, Tp = frames / 2) and walks them in chunks of at most three 32-row groups (72 KB of staging memory
+// and <= 128 VGPRs: two workgroups per CU at any clip length).  A clip that fits one chunk gets the same single-pass
+// epilogue as the uniform kernel (bit-identical results).  A longer clip is done in two passes over its chunks:
+//   pass 1  GEMM of the chunk, raw result to C, per-column statistics carried in registers across the chunks
+//           (forward: count / mean / M2 merged with Chan's formula; backward: the two sums of the InstanceNorm backward);
+//   pass 2  the workgroup re-reads its own raw tile (L2-resident, written by the same lanes) and applies the
+//           normalisation + LeakyReLU (forward) or the InstanceNorm backward (backward) in place.
+// No second launch, no inter-workgroup traffic, the per-(clip, channel) statistics never leave the registers.
+// Reference: detection/modules/conv1d.py:38-42 and its autograd.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kRaggedRG = 3;           // largest chunk, in 32-row groups
+
+// one chunk: rows [bm, bm + 32 RG) of which `rows` are valid.  SINGLE: the clip is this chunk.
+// st0/st1/st2: forward (count, mean, M2) of the column; backward (unused, sum dU, sum dU*u) in-lane partial sums
+extern __shared__ __attribute__((aligned(16))) unsigned char x3_dyn_lds[];    // the ragged kernel's staging memory (dynamic LDS)
+
+// (not inlined: each tile height keeps its own register allocation -- inlined side by side the two K loops cost the
+// kernel 20-40 spilled VGPRs inside the loop)
+template <int RG, int EPI>
+__device__ __attribute__((noinline)) void x3_ragged_chunk(const bool SINGLE, const float* __restrict__ A, int lda, const u32x4* __restrict__ Bpk,
+                                                const float* __restrict__ bias, float* __restrict__ C, int ldc, int N, int K,
+                                                int bm, int rows, int store_rows, int bn,
+                                                float* __restrict__ rstd_clip, const float* __restrict__ act, float& st0,
+                                                float& st1, float& st2) {
+    unsigned char* lds = x3_dyn_lds;
+    // rows: valid rows of the chunk; store_rows (a multiple of 32, <= 32 RG): rows of the clip's allocation under this tile
+    constexpr int MT = 2 * RG;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, kg = lane >> 4;
+    f32x4 acc[MT][1];
+    x3_tile_gemm<RG, 8>(A, lda, Bpk, K, bm, bn, lds, acc, store_rows);
+    const int col = bn + wave * 16 + r16;
+    const float invR = 1.0f / (float)rows;
+    if (EPI == X3_FWD) {
+        const float bv = bias ? bias[col] : 0.f;
+        float s = 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[m][0][e] += bv;
+                if (m * 16 + 4 * kg + e < rows) s += acc[m][0][e];
+            }
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        const float mean = s * invR;
+        float qq = 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (m * 16 + 4 * kg + e < rows) { const float d = acc[m][0][e] - mean; qq += d * d; }
+        qq += __shfl_xor(qq, 16);
+        qq += __shfl_xor(qq, 32);
+        if (SINGLE) {
+            const float rs = 1.0f / sqrtf(qq * invR + 1e-5f);      // biased variance, eps 1e-5 (InstanceNorm1d defaults)
+            if (kg == 0) rstd_clip[col] = rs;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = m * 16 + 4 * kg + e;
+                    const float u = (acc[m][0][e] - mean) * rs;
+                    if (row < store_rows) C[(size_t)(bm + row) * ldc + col] = row < rows ? (u > 0.f ? u : 0.2f * u) : 0.f;
+                }
+        } else {
+            // raw conv output now, statistics merged across the clip's chunks (Chan et al.)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = m * 16 + 4 * kg + e;
+                    if (row < store_rows) C[(size_t)(bm + row) * ldc + col] = row < rows ? acc[m][0][e] : 0.f;
+                }
+            const float nc = (float)rows, nt = st0 + nc, dl = mean - st1;
+            st2 = st2 + qq + dl * dl * (st0 * nc / nt);
+            st1 = st1 + dl * (nc / nt);
+            st0 = nt;
+        }
+    } else {      // X3_BWD
+        float s1 = 0.f, s2 = 0.f;
+        float u[MT][4];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = m * 16 + 4 * kg + e;
+                const float av = act[(size_t)(bm + min(row, store_rows - 1)) * ldc + col];   // unconditional (clamped, masked below)
+                const bool valid = row < rows;
+                const float uv = valid ? (av > 0.f ? av : av * 5.0f) : 0.f;                 // invert LeakyReLU(0.2)
+                const float du = valid ? acc[m][0][e] * (av > 0.f ? 1.f : 0.2f) : 0.f;
+                acc[m][0][e] = du;
+                u[m][e] = uv;
+                s1 += du;
+                s2 += du * uv;
+            }
+        if (SINGLE) {
+            const float rs = rstd_clip[col];
+            s1 += __shfl_xor(s1, 16);
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 16);
+            s2 += __shfl_xor(s2, 32);
+            const float m1 = s1 * invR, m2 = s2 * invR;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = m * 16 + 4 * kg + e;
+                    if (row < store_rows) C[(size_t)(bm + row) * ldc + col] = row < rows ? rs * (acc[m][0][e] - m1 - u[m][e] * m2) : 0.f;
+                }
+        } else {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = m * 16 + 4 * kg + e;
+                    if (row < store_rows) C[(size_t)(bm + row) * ldc + col] = acc[m][0][e];          // dU (zero in padding rows)
+                }
+            st1 += s1;
+            st2 += s2;
+        }
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 4) void gemm_ragged_x3_kernel(const float* __restrict__ A, int lda, const u32x4* __restrict__ Bpk,
+                                                                const float* __restrict__ bias, float* __restrict__ C, int ldc,
+                                                                const int* __restrict__ frame_off, const int* __restrict__ pool_off,
+                                                                int N, int K, int tiles_n, int ntiles, float* __restrict__ rstd_io,
+                                                                const float* __restrict__ act) {
+    // blocks b and b + 8 share an XCD (observed round-robin placement; speed only): the slabs of one clip stay on one XCD
+    // (its rows are read once into that L2), and clips are dealt to the XCDs round-robin -- batches arrive sorted by
+    // length, a contiguous range per XCD would give one XCD all the long clips
+    int clip, slab;
+    {
+        const int id = blockIdx.x, nclips = ntiles / tiles_n;
+        if ((nclips & 7) == 0) {
+            const int j = id >> 3;
+            clip = (j / tiles_n) * 8 + (id & 7);
+            slab = j % tiles_n;
+        } else {
+            clip = id / tiles_n;
+            slab = id % tiles_n;
+        }
+    }
+    const int bn = slab * 128;
+    const int Tp = (frame_off[clip + 1] - frame_off[clip]) / 2;
+    const int row0 = pool_off[clip];
+    if (Tp < 1) return;
+    const int G = (Tp + 31) >> 5;                                   // 32-row groups of the clip
+    const int nchunk = (G + kRaggedRG - 1) / kRaggedRG;
+    const int gbase = G / nchunk, grem = G % nchunk;                // balanced: the first `grem` chunks take one group more
+    float* rstd_clip = rstd_io + (size_t)clip * N;
+    float st0 = 0.f, st1 = 0.f, st2 = 0.f;
+    const bool single = nchunk == 1;
+    int g0 = 0;
+    for (int c = 0; c < nchunk; ++c) {
+        const int ng = gbase + (c < grem ? 1 : 0);
+        const int bm = row0 + 32 * g0;
+        const int rows = min(32 * ng, Tp - 32 * g0);
+        if (c) __syncthreads();                                     // every wave is done with the previous chunk's staging memory
+        // two tile heights only (a one-group chunk runs as a two-group tile whose second group is padding: the K-order of
+        // every output element is the same at any tile height, so the results do not depend on the choice)
+        if (ng <= 2) x3_ragged_chunk<2, EPI>(single, A, lda, Bpk, bias, C, ldc, N, K, bm, rows, 32 * ng, bn, rstd_clip, act, st0, st1, st2);
+        else x3_ragged_chunk<3, EPI>(single, A, lda, Bpk, bias, C, ldc, N, K, bm, rows, 32 * ng, bn, rstd_clip, act, st0, st1, st2);
+        g0 += ng;
+    }
+    if (single) return;
+    // ---- pass 2: this lane's column of every row, read back from the raw tile it wrote ----
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int col = bn + wave * 16 + r16;
+    const float invT = 1.0f / (float)Tp;
+    const int npad = 32 * G;
+    if (EPI == X3_FWD) {
+        const float mean = st1;
+        const float rs = 1.0f / sqrtf(st2 * invT + 1e-5f);
+        if (kg == 0) rstd_clip[col] = rs;
+        for (int r = 4 * kg; r < npad; r += 16) {
+            float z[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) z[e] = C[(size_t)(row0 + r + e) * ldc + col];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float u = (z[e] - mean) * rs;
+                C[(size_t)(row0 + r + e) * ldc + col] = (r + e < Tp) ? (u > 0.f ? u : 0.2f * u) : 0.f;
+            }
+        }
+    } else {
+        float s1 = st1, s2 = st2;
+        s1 += __shfl_xor(s1, 16);
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 16);
+        s2 += __shfl_xor(s2, 32);
+        const float m1 = s1 * invT, m2 = s2 * invT, rs = rstd_clip[col];
+        for (int r = 4 * kg; r < npad; r += 16) {
+            float du[4], av[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                du[e] = C[(size_t)(row0 + r + e) * ldc + col];
+                av[e] = act[(size_t)(row0 + r + e) * ldc + col];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float uv = av[e] > 0.f ? av[e] : av[e] * 5.0f;
+                C[(size_t)(row0 + r + e) * ldc + col] = (r + e < Tp) ? rs * (du[e] - m1 - uv * m2) : 0.f;
+            }
+        }
+    }
+}
+
+// epi: 1 forward (conv + InstanceNorm + LeakyReLU), 2 backward (data gradient + InstanceNorm/LeakyReLU backward of the
+// previous block); frame_off / pool_off: the batch's device tables
+void launch_gemm_ragged_x3(const float* A, int lda, const void* Bpk, const float* bias, float* C, int ldc, int B,
+                           const int* frame_off, const int* pool_off, int N, int K, int epi, float* rstd_io, const float* act,
+                           hipStream_t st) {
+    const int tn = N / 128;
+    constexpr size_t kLds = 2 * 2 * 3 * (2 * kRaggedRG) * 1024;      // two K tiles of the tallest chunk
+    if (epi == X3_FWD)
+        hipLaunchKernelGGL((gemm_ragged_x3_kernel<X3_FWD>), dim3(tn * B), dim3(512), kLds, st, A, lda, (const u32x4*)Bpk, bias, C, ldc,
+                           frame_off, pool_off, N, K, tn, tn * B, rstd_io, act);
+    else
+        hipLaunchKernelGGL((gemm_ragged_x3_kernel<X3_BWD>), dim3(tn * B), dim3(512), kLds, st, A, lda, (const u32x4*)Bpk, bias, C, ldc,
+                           frame_off, pool_off, N, K, tn, tn * B, rstd_io, act);
 }
 
 // ---------------------------------------------------------------------------------------------------

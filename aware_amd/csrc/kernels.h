@@ -106,6 +106,10 @@ bool gemm_clip_x3_supported(int nwm, int N, int K, int lda);
 void launch_gemm_clip_x3(const float* A, int lda, const void* Bpk, const float* bias, float* C, int ldc, int B, int nwm,
                          int Tp, int N, int K, int epi, float* rstd_io, const float* act, hipStream_t st,
                          const void* lastpk = nullptr, float* zpart = nullptr, int CL = 0);
+// the same block for ragged batches / clips of any length (one launch; clips longer than 96 pooled frames in two passes)
+void launch_gemm_ragged_x3(const float* A, int lda, const void* Bpk, const float* bias, float* C, int ldc, int B,
+                           const int* frame_off, const int* pool_off, int N, int K, int epi, float* rstd_io, const float* act,
+                           hipStream_t st);
 // fused read-out of the embed loop: last conv block + BRH + loss + their backward + data gradient of the last conv
 // + backward of the previous block's norm/activation (uniform batches; see gemm_x3.hip)
 bool readout_x3_supported(int nwm, int ci, int C);
