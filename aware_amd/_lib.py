@@ -34,13 +34,17 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     bdir = os.path.join(CSRC, "build")
     os.makedirs(bdir, exist_ok=True)
     flags = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"]
+    # per-file flags.  The FFT kernels are VALU-issue bound and gfx950 issues a packed-f32 instruction (v_pk_fma_f32 ...)
+    # in the time of two scalar ones, so the SLP vectoriser's packing only adds the v_mov traffic that lines registers up
+    # in pairs: measured fewer cycles per frame with it off.
+    extra = {"dsp_stream.hip": ["-fno-slp-vectorize"]}
     jobs, objs = [], []
     for sname in SOURCES:
         src = os.path.join(CSRC, sname)
         obj = os.path.join(bdir, sname.replace(".hip", ".o"))
         objs.append(obj)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
-            jobs.append(["hipcc"] + flags + ["-c", src, "-o", obj])
+            jobs.append(["hipcc"] + flags + extra.get(sname, []) + ["-c", src, "-o", obj])
     if not jobs and os.path.exists(LIB_PATH) and all(os.path.getmtime(o) <= os.path.getmtime(LIB_PATH) for o in objs):
         return LIB_PATH
 
