@@ -98,6 +98,9 @@ SIGNATURES = {
     "aware_waveform_normalize_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "aware_nadam_coefficients": (_i, [_i, _f, _f, _f, _f, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "aware_nadam_clamp_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, C.POINTER(C.c_float), _f, _f, _f, _vp]),
+    "aware_detector_train_workspace_bytes": (_sz, [_vp, _vp]),
+    "aware_detector_weight_gradients": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _vp, _sz, _vp]),
+    "aware_detector_update": (_i, [_vp, _vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "aware_detector_create": (_i, [C.POINTER(_vp), _vp, _vp, _i, _i, _pi, C.POINTER(_vp), C.POINTER(_vp)]),
     "aware_detector_destroy": (None, [_vp]),
     "aware_detect_workspace_bytes": (_sz, [_vp, _vp]),

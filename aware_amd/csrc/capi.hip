@@ -71,6 +71,7 @@ struct aware_batch {
 
 struct aware_detector {
     int n_mels = 0, n_layers = 0, nbits = 0;
+    int band_lo = 0, nband = 0;
     int ch[8] = {0};
     int maxc = 0;
     float* mem = nullptr;
@@ -368,24 +369,19 @@ extern "C" int aware_istft_bwd(const aware_plan* plan, const aware_batch* b, con
 }
 
 // ---------------------------------------------------------------------------------------------
-extern "C" int aware_detector_create(aware_detector** out, const aware_plan* plan, const float* mel_basis, int n_mels,
-                                     int n_layers, const int* channels, const float* const* weights,
-                                     const float* const* biases) {
-    if (!out || !plan || !mel_basis || !channels || !weights) return AWARE_E_BADARG;
-    if (n_mels != 128 || n_layers < 1 || n_layers > 7 || channels[0] != n_mels) return AWARE_E_UNSUPPORTED;
-    const int cl = channels[n_layers];
-    if (cl % 2 || cl > 64) return AWARE_E_UNSUPPORTED;
-    for (int i = 0; i <= n_layers; ++i)
-        if (channels[i] % 4) return AWARE_E_UNSUPPORTED;
-    aware_detector* d = new aware_detector();
-    d->n_mels = n_mels; d->n_layers = n_layers; d->nbits = cl / 2;
+extern "C" void aware_detector_destroy(aware_detector* d);
+// host staging of the detector's parameters (plain + transposed f32 copies, bf16x3 fragment images) and upload; `alloc`
+// = false re-uses the device buffers of a detector created with the same shapes (aware_detector_update)
+static int detector_upload(aware_detector* d, const float* mel_basis, const float* const* weights,
+                           const float* const* biases, bool alloc) {
+    const int n_mels = d->n_mels, n_layers = d->n_layers;
+    const int* channels = d->ch;
     size_t total = (size_t)n_mels * kFS * 2;
-    for (int i = 0; i <= n_layers; ++i) { d->ch[i] = channels[i]; if (channels[i] > d->maxc) d->maxc = channels[i]; }
     for (int i = 0; i < n_layers; ++i) total += (size_t)channels[i] * channels[i + 1] * 2 + channels[i + 1];
     std::vector<float> h(total, 0.f);
     size_t o = 0;
     const int nbins = kNfft / 2 + 1;
-    const int lo = plan->dev.band_lo, nb = plan->dev.nband;
+    const int lo = d->band_lo, nb = d->nband;
     size_t o_melT = o; o += (size_t)n_mels * kFS;
     size_t o_melB = o; o += (size_t)kFS * n_mels;
     // only the in-band columns of the mel basis ever multiply non-zero magnitudes
@@ -410,7 +406,7 @@ extern "C" int aware_detector_create(aware_detector** out, const aware_plan* pla
             }
         for (int r = 0; r < co; ++r) h[o_b[l] + r] = biases && biases[l] ? biases[l][r] : 0.f;
     }
-    HIPCHK(hipMalloc((void**)&d->mem, total * sizeof(float)));
+    if (alloc) HIPCHK(hipMalloc((void**)&d->mem, total * sizeof(float)));
     HIPCHK(hipMemcpy(d->mem, h.data(), total * sizeof(float), hipMemcpyHostToDevice));
     d->melT = d->mem + o_melT;
     d->melB = d->mem + o_melB;
@@ -452,7 +448,7 @@ extern "C" int aware_detector_create(aware_detector** out, const aware_plan* pla
             if (o_pk[l] != (size_t)-1) x3_pack(h.data() + o_w[l], co, ci, hp.data() + o_pk[l] / 2);
             if (o_pkT[l] != (size_t)-1) x3_pack(h.data() + o_wT[l], ci, co, hp.data() + o_pkT[l] / 2);
         }
-        HIPCHK(hipMalloc(&d->pkmem, pk_total + 16));
+        if (alloc) HIPCHK(hipMalloc(&d->pkmem, pk_total + 16));
         HIPCHK(hipMemcpy(d->pkmem, hp.data(), pk_total, hipMemcpyHostToDevice));
         if (ro) { d->lastpk = (char*)d->pkmem + o_lp; d->lastTpk = (char*)d->pkmem + o_lT; }
         d->melTpk = (char*)d->pkmem + o_mT;
@@ -462,8 +458,34 @@ extern "C" int aware_detector_create(aware_detector** out, const aware_plan* pla
             if (o_pkT[l] != (size_t)-1) d->wTpk[l] = (char*)d->pkmem + o_pkT[l];
         }
     }
+    return AWARE_OK;
+}
+
+extern "C" int aware_detector_create(aware_detector** out, const aware_plan* plan, const float* mel_basis, int n_mels,
+                                     int n_layers, const int* channels, const float* const* weights,
+                                     const float* const* biases) {
+    if (!out || !plan || !mel_basis || !channels || !weights) return AWARE_E_BADARG;
+    if (n_mels != 128 || n_layers < 1 || n_layers > 7 || channels[0] != n_mels) return AWARE_E_UNSUPPORTED;
+    const int cl = channels[n_layers];
+    if (cl % 2 || cl > 64) return AWARE_E_UNSUPPORTED;
+    for (int i = 0; i <= n_layers; ++i)
+        if (channels[i] % 4) return AWARE_E_UNSUPPORTED;
+    aware_detector* d = new aware_detector();
+    d->n_mels = n_mels; d->n_layers = n_layers; d->nbits = cl / 2;
+    d->band_lo = plan->dev.band_lo; d->nband = plan->dev.nband;
+    for (int i = 0; i <= n_layers; ++i) { d->ch[i] = channels[i]; if (channels[i] > d->maxc) d->maxc = channels[i]; }
+    int rc = detector_upload(d, mel_basis, weights, biases, true);
+    if (rc) { aware_detector_destroy(d); return rc; }
     *out = d;
     return AWARE_OK;
+}
+// EXTENSION (detector training, BASELINE north_star; the reference never changes the weights): replace the parameters of a
+// detector in place (same layer shapes).  Host arrays as for aware_detector_create.  Synchronous (blocking copies); the
+// caller makes sure no work using the detector is in flight.
+extern "C" int aware_detector_update(aware_detector* d, const float* mel_basis, const float* const* weights,
+                                     const float* const* biases) {
+    if (!d || !mel_basis || !weights) return AWARE_E_BADARG;
+    return detector_upload(d, mel_basis, weights, biases, false);
 }
 extern "C" void aware_detector_destroy(aware_detector* d) {
     if (!d) return;
@@ -645,6 +667,12 @@ struct DetGradCtx {
     float *d1 = nullptr, *d2 = nullptr;   // gradient ping-pong [NP][maxc]
     float* gmag = nullptr;            // out: [NF][256]
     const float* loss_add = nullptr;  // [B] per-clip term added to the loss before the best-loss bookkeeping (L1 part), or null
+    // EXTENSION (detector training): also the parameter gradients dL/dW_l [Cout][Cin], dL/db_l [Cout]; tr1 / tr2 are
+    // scratch for the transposed operands, [maxc][NP] each.  Forces the three-kernel read-out (it writes dL/dZ of the
+    // last block to memory).
+    float* const* wgrad = nullptr;
+    float* const* bgrad = nullptr;
+    float *tr1 = nullptr, *tr2 = nullptr;
 };
 static int det_forward_backward(const aware_detector* d, const aware_batch* b, const float* mag, DetBufs& db,
                                 const DetGradCtx& G, hipStream_t st) {
@@ -653,7 +681,7 @@ static int det_forward_backward(const aware_detector* d, const aware_batch* b, c
     // one kernel for the last conv block, the BRH head, the loss, their backward and the data gradient of the last
     // conv (uniform batches, bf16x3 configuration); otherwise split-K GEMM + tail kernel + data-gradient GEMM
     const int pipe = G.pipe;
-    const bool fused_readout = G.readout == 0 && pipe == 0 && nwm && nl >= 2 && d->lastpk && G.target &&
+    const bool fused_readout = G.readout == 0 && !G.wgrad && pipe == 0 && nwm && nl >= 2 && d->lastpk && G.target &&
                                readout_x3_supported(nwm, d->ch[nl - 1], d->ch[nl]) && d->wpk[nl - 2] &&
                                gemm_clip_x3_supported(nwm, d->ch[nl - 1], d->ch[nl - 2], d->ch[nl - 2]);
     int rc = det_forward(d, b, mag, db, st, pipe, fused_readout);
@@ -683,6 +711,17 @@ static int det_forward_backward(const aware_detector* d, const aware_batch* b, c
         if (!dz_ready) {
             launch_in_lrelu_bwd(dA, db.act[l], b->d_frame_off, b->d_pool_off, db.rstd[l], co, b->B, b->max_frames / 2, st);
             LAUNCHCHK(); PROF(K_INLRELU);
+        }
+        if (G.wgrad && G.wgrad[l]) {
+            // dA = dL/dZ_l [NP][co] (zero in padding rows), X = input of the block [NP][ci]:  dW = dZ^T X as an NT GEMM over
+            // the transposed operands (K = NP contiguous); db = column sums of dZ (zero up to rounding: the InstanceNorm
+            // behind the convolution removes any per-channel constant)
+            const float* X = l > 0 ? db.act[l - 1] : db.x0;
+            launch_transpose(dA, G.tr1, b->NP, co, st);
+            launch_transpose(X, G.tr2, b->NP, ci, st);
+            launch_gemm_nt(G.tr1, b->NP, G.tr2, b->NP, nullptr, G.wgrad[l], ci, co, ci, b->NP, st);
+            if (G.bgrad && G.bgrad[l]) launch_colsum(dA, G.bgrad[l], b->NP, co, st);
+            LAUNCHCHK(); PROF(K_MISC);
         }
         if (nwm && l > 0 && ci >= 128) {
             // data-gradient GEMM whose epilogue is the backward of block l-1's InstanceNorm+LeakyReLU
@@ -736,6 +775,41 @@ extern "C" int aware_detector_backward(const aware_detector* d, const aware_batc
     G.loss = c.take<float>(b->B);
     if (!c.ok) return AWARE_E_WORKSPACE;
     G.target = grad_values; G.loss_kind = AWARE_LOSS_EXTERNAL; G.gmag = grad_mag;
+    int rc = det_forward_backward(d, b, mag, o, G, st);
+    if (rc) return rc;
+    if (values) HIPCHK(hipMemcpyAsync(values, o.pred, (size_t)b->B * d->nbits * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return AWARE_OK;
+}
+
+// EXTENSION (BASELINE north_star "gradients ... all-reduce"; the reference freezes the detector, multibit_embedder.py:76-77,
+// and trains nothing): forward + backward of the network INCLUDING the parameter gradients, for a data-parallel detector
+// training step -- the caller all-reduces grad_weights / grad_biases across ranks (RCCL) and applies its optimiser, then
+// refreshes the device copy with aware_detector_update.  grad_weights / grad_biases: host arrays of n_layers device
+// pointers ([Cout][Cin] and [Cout] f32; entries may be NULL).
+extern "C" size_t aware_detector_train_workspace_bytes(const aware_batch* b, const aware_detector* d) {
+    if (!b || !d) return 0;
+    return aware_detector_backward_workspace_bytes(b, d) + (size_t)b->NP * d->maxc * sizeof(float) * 2 + 1024;
+}
+extern "C" int aware_detector_weight_gradients(const aware_detector* d, const aware_batch* b, const float* mag,
+                                               const float* grad_values, float* values, float* grad_mag,
+                                               float* const* grad_weights, float* const* grad_biases, void* workspace,
+                                               size_t workspace_bytes, void* stream) {
+    if (!d || !b || !mag || !grad_values || !grad_mag || !grad_weights || !workspace) return AWARE_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    Carver c(workspace, workspace_bytes);
+    DetBufs o;
+    carve_det(c, b, d, o);
+    DetGradCtx G;
+    G.d1 = c.take<float>((size_t)b->NP * d->maxc);
+    G.d2 = c.take<float>((size_t)b->NP * d->maxc);
+    G.tr1 = c.take<float>((size_t)b->NP * d->maxc);
+    G.tr2 = c.take<float>((size_t)b->NP * d->maxc);
+    G.loss = c.take<float>(b->B);
+    if (!c.ok) return AWARE_E_WORKSPACE;
+    // padding rows of the gradient ping-pong buffers take part in the row contraction: keep them finite
+    HIPCHK(hipMemsetAsync(G.d1, 0, (size_t)b->NP * d->maxc * sizeof(float) * 2, st));
+    G.target = grad_values; G.loss_kind = AWARE_LOSS_EXTERNAL; G.gmag = grad_mag;
+    G.wgrad = grad_weights; G.bgrad = grad_biases; G.readout = 1; G.pipe = 1;      // exact-f32 pipe for the training step
     int rc = det_forward_backward(d, b, mag, o, G, st);
     if (rc) return rc;
     if (values) HIPCHK(hipMemcpyAsync(values, o.pred, (size_t)b->B * d->nbits * sizeof(float), hipMemcpyDeviceToDevice, st));

@@ -144,6 +144,8 @@ void launch_polar_decompose_bwd(const void* spec, const float* gmag, const float
 void launch_polar_assemble(const float* mag, const float* phase, void* spec, size_t n, hipStream_t st);
 void launch_polar_assemble_bwd(const float* mag, const float* phase, const void* gspec, float* gmag, float* gphase, size_t n,
                                hipStream_t st);
+void launch_transpose(const float* in, float* out, int R, int C, hipStream_t st);
+void launch_colsum(const float* in, float* out, int R, int C, hipStream_t st);
 void launch_normalize_bwd(const float* x, const float* g, float* dx, const int* off, const int* len, int B, hipStream_t st);
 void launch_nadam_clamp(float* p, const float* g, float* m, float* v, const float* lo, const float* hi, size_t n, float c_grad,
                         float c_mom, float bias_corr2, float beta1, float beta2, float eps, hipStream_t st);

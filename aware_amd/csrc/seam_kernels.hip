@@ -106,6 +106,44 @@ __global__ __launch_bounds__(256) void nadam_clamp_kernel(float* __restrict__ p,
     }
 }
 
+// out[c][r] = in[r][c] for in [R][C] row-major (32 x 32 tiles through LDS, both sides coalesced).  Used to turn the
+// weight-gradient contraction over rows, dW = dZ^T X, into the K-contiguous NT form of the GEMM kernels.
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? in[(size_t)r * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < C && r < R) out[(size_t)c * R + r] = tile[tx][i];
+    }
+}
+// out[c] = sum_r in[r][c]  (bias gradient; f64 accumulation, fixed order)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C) {
+    __shared__ double red[8][32];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
+    double s = 0.0;
+    if (c < C)
+        for (int r = g; r < R; r += 8) s += (double)in[(size_t)r * C + c];
+    red[g][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        double t = 0.0;
+        for (int i = 0; i < 8; ++i) t += red[i][threadIdx.x & 31];
+        out[c] = (float)t;
+    }
+}
+void launch_transpose(const float* in, float* out, int R, int C, hipStream_t st) {
+    hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, st, in, out, R, C);
+}
+void launch_colsum(const float* in, float* out, int R, int C, hipStream_t st) {
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + 31) / 32), dim3(256), 0, st, in, out, R, C);
+}
+
 static inline unsigned gridn(size_t n) {
     size_t g = (n + 255) / 256;
     return (unsigned)(g < 1 ? 1 : (g > 16384 ? 16384 : g));

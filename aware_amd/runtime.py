@@ -229,6 +229,25 @@ def detector_backward(plan: Plan, det: "DetectorWeights", batch: Batch, mag: tor
     return vals, gmag
 
 
+def detector_weight_gradients(plan: Plan, det: "DetectorWeights", batch: Batch, mag: torch.Tensor, grad_values: torch.Tensor):
+    """EXTENSION (detector training): (values, grad_mag, [dL/dW_l], [dL/db_l]) of the network for the upstream gradient
+    grad_values [B, n_bits] (aware_detector_weight_gradients)."""
+    lib = plan.lib
+    nbytes = lib.aware_detector_train_workspace_bytes(batch.h, det.h)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=mag.device)
+    vals = torch.empty((batch.B, det.n_bits), dtype=torch.float32, device=mag.device)
+    gmag = torch.empty((batch.total_frames, SPEC_STRIDE), dtype=torch.float32, device=mag.device)
+    ch = det.channels
+    gw = [torch.empty((ch[i + 1], ch[i]), dtype=torch.float32, device=mag.device) for i in range(len(ch) - 1)]
+    gb = [torch.empty((ch[i + 1],), dtype=torch.float32, device=mag.device) for i in range(len(ch) - 1)]
+    pw = (C.c_void_p * len(gw))(*[t.data_ptr() for t in gw])
+    pb = (C.c_void_p * len(gb))(*[t.data_ptr() for t in gb])
+    gv = grad_values.contiguous().float()
+    check(lib.aware_detector_weight_gradients(det.h, batch.h, _ptr(mag), _ptr(gv), _ptr(vals), _ptr(gmag), pw, pb, _ptr(ws), nbytes,
+                                              _stream()), "aware_detector_weight_gradients")
+    return vals, gmag, gw, gb
+
+
 class DetectorWeights:
     """Device copy of the frozen detector (aware_detector)."""
 
@@ -237,6 +256,7 @@ class DetectorWeights:
         self.lib = load_library()
         self.plan = plan
         mel = np.ascontiguousarray(mel_basis, dtype=np.float32)
+        self._mel = mel
         ws = [np.ascontiguousarray(w, dtype=np.float32) for w in weights]
         bs = [np.ascontiguousarray(b, dtype=np.float32) for b in biases]
         chans = [ws[0].shape[1]] + [w.shape[0] for w in ws]
@@ -250,6 +270,15 @@ class DetectorWeights:
                                             (C.c_int * (nl + 1))(*chans), wp, bp)
         check(rc, "aware_detector_create")
         self.h = h
+
+    def update(self, weights, biases):
+        """EXTENSION (detector training): replace the parameters in place (same shapes), aware_detector_update."""
+        torch.cuda.synchronize()
+        ws = [np.ascontiguousarray(w, dtype=np.float32) for w in weights]
+        bs = [np.ascontiguousarray(b, dtype=np.float32) for b in biases]
+        wp = (C.c_void_p * len(ws))(*[w.ctypes.data for w in ws])
+        bp = (C.c_void_p * len(bs))(*[b.ctypes.data for b in bs])
+        check(self.lib.aware_detector_update(self.h, C.c_void_p(self._mel.ctypes.data), wp, bp), "aware_detector_update")
 
     def __del__(self):
         try:

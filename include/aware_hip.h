@@ -164,6 +164,20 @@ int aware_detector_backward(const aware_detector* det, const aware_batch* batch,
                             const float* grad_values, float* values, float* grad_mag, void* workspace,
                             size_t workspace_bytes, void* stream);
 
+/* EXTENSION -- detector training step (BASELINE.json north_star: "RCCL all-reduce over xGMI on the embedder/detector
+ * gradients"; the reference freezes the detector, multibit_embedder.py:76-77, and trains nothing: parity unpinned, specified
+ * by torch autograd on the oracle's Detector).  aware_detector_weight_gradients = aware_detector_backward plus
+ * dL/dW_l [Cout][Cin] and dL/db_l [Cout] of every conv block (grad_weights / grad_biases: host arrays of n_layers device
+ * pointers, entries may be NULL); the caller all-reduces them over its ranks, applies its optimiser and writes the new
+ * parameters back with aware_detector_update (host arrays as for aware_detector_create, same shapes, synchronous). */
+size_t aware_detector_train_workspace_bytes(const aware_batch* batch, const aware_detector* det);
+int aware_detector_weight_gradients(const aware_detector* det, const aware_batch* batch, const float* mag,
+                                    const float* grad_values, float* values, float* grad_mag,
+                                    float* const* grad_weights, float* const* grad_biases, void* workspace,
+                                    size_t workspace_bytes, void* stream);
+int aware_detector_update(aware_detector* det, const float* mel_basis, const float* const* weights,
+                          const float* const* biases);
+
 /* ---- embedder -----------------------------------------------------------------------------------
  * AWAREEmbedder.embed / _optimize (embedding/multibit_embedder.py:70-197), batched and ragged:
  * every clip is its own optimisation problem.  loss: AWARE_LOSS_* above -- 0 push_extremes, 1 mse, 2 hinge, 3 sign,

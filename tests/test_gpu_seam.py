@@ -198,3 +198,57 @@ def test_push_extremes_l1_extension(env):
     # staged DSP kernels do not carry the L1 term: refused, not ignored
     with pytest.raises(Exception):
         rt.EmbedSession(plan, dw, batch, loss="push_extremes_l1", l1_weight=lam, dsp_path="staged")
+
+
+def test_detector_weight_gradients_extension(env):
+    """EXTENSION (detector training; no reference counterpart, parity unpinned -- the oracle's Detector under torch
+    autograd is the specification): dL/dW and dL/db of every conv block and dL/dmag for a random upstream gradient, on a
+    ragged batch; then one DetectorTrainer step changes the device weights consistently with the host copy."""
+    rt, emb, det, O = env
+    from aware_amd.utils.audio import get_plan
+    plan = get_plan()
+    dw = emb.detection_net.device_weights(plan)
+    g = torch.Generator().manual_seed(9)
+    lengths = [16000, 24000]
+    clips = [make_clip(300 + i, n)[0] for i, n in enumerate(lengths)]
+    batch = rt.Batch(lengths)
+    x = batch.pack(clips)
+    mag, _ = rt.stft_band(plan, batch, x, normalize=True)
+    cot = torch.randn(2, 20, generator=g)
+    vals, gmag, gw, gb = rt.detector_weight_gradients(plan, dw, batch, mag, cot.cuda())
+    torch.cuda.synchronize()
+    od = O.Detector()
+    ws = [w.clone().requires_grad_(True) for w in od.ws]
+    bs = [b.clone().requires_grad_(True) for b in od.bs]
+    od.ws, od.bs = ws, bs
+    oe = O.Embedder()
+    total = 0.0
+    for i, c in enumerate(clips):
+        a = torch.from_numpy(c)[None]
+        m = torch.abs(O.stft(a / torch.amax(torch.abs(a) + 1e-8))).clone()
+        m[:, oe.nonband] = 0.0
+        out = od.forward(m)
+        np.testing.assert_allclose(vals[i].cpu().numpy(), out[0].detach().numpy(), atol=5e-5)
+        total = total + (out[0] * cot[i]).sum()
+    total.backward()
+    for l in range(4):
+        ref = ws[l].grad
+        rel = float((gw[l].cpu() - ref).norm() / ref.norm())
+        print(f"layer {l}: dL/dW rel L2 vs autograd {rel:.2e}; |dL/db| max {float(gb[l].abs().max()):.1e} (autograd {float(bs[l].grad.abs().max()):.1e})")
+        assert rel < 2e-4, (l, rel)
+        # the InstanceNorm behind every convolution removes per-channel constants: bias gradients vanish up to rounding
+        assert float(gb[l].abs().max()) < 1e-4 * float(ref.abs().max()) * ref.shape[1]
+    # one training step: device and host weights move together, the detector still works
+    from aware_amd.training import DetectorTrainer
+    from aware_amd.utils.models import load
+    emb2, det2 = load()
+    w_before = [w.copy() for w in det2.detection_net.weights]
+    bits = torch.randint(0, 2, (2, 20), generator=g).to(torch.int32).cuda()
+    tr = DetectorTrainer(det2, lr=1e-3)
+    l0, raw0 = tr.step(rt.Ragged(x, lengths), bits)
+    l1, raw1 = tr.step(rt.Ragged(x, lengths), bits)
+    assert np.isfinite(l0) and np.isfinite(l1) and l1 < l0            # two Adam steps on the same batch reduce its loss
+    assert any(float(np.abs(a - b).max()) > 0 for a, b in zip(w_before, det2.detection_net.weights))
+    v = det2.detect_batch(clips, 16000)
+    assert bool(torch.isfinite(v).all())
+    np.testing.assert_allclose(v.cpu().numpy(), rt.detect(plan, det2.detection_net.device_weights(plan), batch, x).cpu().numpy(), atol=1e-6)
