@@ -829,7 +829,8 @@ struct aware_embed {
     // signals [NS]
     float *yraw, *oob, *gy;
     float* gpad;          // [B][2][512] reflect-pad parts of the synthesis adjoint (streaming DSP kernels)
-    // loss push_extremes + L1 (EXTENSION): original coefficients, per-run partial sums of |c - c0|, per-clip loss term
+    // original coefficients (the streaming analysis adjoint recomputes the box from them; also the L1 term's reference);
+    // loss push_extremes + L1 (EXTENSION): per-run partial sums of |c - c0|, per-clip loss term
     float* c0 = nullptr;
     double* pl1 = nullptr;
     float* l1term = nullptr;
@@ -954,10 +955,10 @@ extern "C" int aware_embed_create(aware_embed** out, const aware_plan* plan, con
     e->pmaxA = c.take<unsigned long long>((size_t)b->B * b->pstride);
     e->pmaxY = c.take<unsigned long long>((size_t)b->B * b->pstride);
     e->pdot = c.take<double>((size_t)b->B * b->pstride);
+    e->c0 = c.take<float>(nsp);
     if (cfg->loss == AWARE_LOSS_PUSH_L1) {
         // the L1 term lives in the streaming DSP kernels only
         if (cfg->dsp_path != 0 || !stream_supported(plan->dev)) { delete e; return AWARE_E_UNSUPPORTED; }
-        e->c0 = c.take<float>(nsp);
         e->pl1 = c.take<double>((size_t)b->B * b->pstride);
         e->l1term = c.take<float>(b->B);
     }
@@ -1051,9 +1052,8 @@ extern "C" int aware_embed_begin(aware_embed* e, const float* audio, const float
                         b->max_frames, st);
     LAUNCHCHK();
     const float ratio = (float)pow(10.0, -(double)e->cfg.tolerance_db / 20.0);
-    launch_embed_prepare(e->mag, e->coef, e->lo, e->hi, e->mom, e->vel, e->best, ratio, (size_t)b->NF * kFS, st);
+    launch_embed_prepare(e->mag, e->coef, e->lo, e->hi, e->mom, e->vel, e->best, e->c0, ratio, (size_t)b->NF * kFS, st);
     LAUNCHCHK();
-    if (e->c0) HIPCHK(hipMemcpyAsync(e->c0, e->coef, (size_t)b->NF * kFS * sizeof(float), hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(e->target, target, (size_t)b->B * e->det->nbits * sizeof(float), hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemsetAsync(e->step, 0, 4 * sizeof(int), st));
     // best_loss = +inf (0x7F800000)
@@ -1070,11 +1070,11 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
     SynthLaunch S;
     S.plan = e->plan->dev; S.frame_off = b->d_frame_off; S.B = b->B; S.max_frames = b->max_frames; S.run_blocks = b->synth_run;
     S.amp = e->coef; S.ph = e->P; S.out = e->yraw; S.add = e->oob; S.pmax = e->pmaxY; S.pstride = b->pstride;
-    S.c0 = e->c0; S.pl1 = e->pl1;
+    S.c0 = e->pl1 ? e->c0 : nullptr; S.pl1 = e->pl1;
     const int dsp = e->cfg.dsp_path;
     run_synth(S, dsp, st);
     LAUNCHCHK(); PROF(K_SYNTH);
-    if (e->c0) {
+    if (e->pl1) {
         launch_l1_reduce(e->pl1, b->d_pc_syn, b->pstride, b->d_frame_off, e->plan->dev.nband, e->cfg.l1_weight, e->l1term, b->B, st);
         LAUNCHCHK(); PROF(K_MISC);
     }
@@ -1114,7 +1114,8 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
     LA.improved = e->improved; LA.sched = e->sched; LA.sched_len = e->cfg.num_iterations + 1; LA.step = e->step;
     LA.grad_out = grad_out; LA.do_step = do_step;
     memcpy(LA.hyp, e->hyp, sizeof(LA.hyp));
-    LA.gpad = e->gpad; LA.c0 = e->c0; LA.l1_weight = e->cfg.l1_weight;
+    LA.gpad = e->gpad; LA.c0 = e->c0; LA.box_ratio = (float)pow(10.0, -(double)e->cfg.tolerance_db / 20.0);
+    LA.l1_weight = e->pl1 ? e->cfg.l1_weight : 0.f;
     run_analysis(LA, dsp, st);
     LAUNCHCHK(); PROF(K_ANALYSIS_ADJ);
     return AWARE_OK;

@@ -30,6 +30,15 @@ __device__ __forceinline__ void nadam_clamp_update(float& p, float& mo, float& v
     p = fminf(fmaxf(p, blo), bhi);
 }
 
+// The tolerance box of a coefficient (embedding/multibit_embedder.py:157-160): d = c0 * 10^(-tol/20),
+// lo = max(c0 - d, 0), hi = c0 + d.  Explicitly rounded operations (no fused multiply-add), so that the kernel that
+// stores the box and the kernel that recomputes it from c0 agree bit for bit.
+__device__ __forceinline__ void box_bounds(float c0, float ratio, float& lo, float& hi) {
+    const float d = __fmul_rn(c0, ratio);
+    lo = fmaxf(__fsub_rn(c0, d), 0.f);
+    hi = __fadd_rn(c0, d);
+}
+
 enum { AN_NORM = 0, AN_ADJ = 1 };
 enum { SY_FWD = 0, SY_ADJ = 1 };
 
@@ -67,8 +76,9 @@ struct AnalysisArgs {
     // streaming wave kernels only (dsp_stream.hip)
     const float* gpad;                // AN_ADJ: [B][2][512] reflect-pad parts of the synthesis adjoint, folded in on load
     int write_pad;                    // AN_NORM: also write the zero tail (columns nband..255) of mag / unit rows
-    const float* c0;                  // AN_ADJ, loss push_extremes + L1 (EXTENSION): original coefficients [NF][kFS], else null
-    float l1_weight;                  //   dL/dc += l1_weight * sign(c - c0) / (nband * T)
+    const float* c0;                  // AN_ADJ (streaming): original coefficients [NF][kFS]; the clamp's box is recomputed from
+    float box_ratio;                  //   them (one operand instead of lo and hi): box_bounds(c0, box_ratio)
+    float l1_weight;                  // loss push_extremes + L1 (EXTENSION): dL/dc += l1_weight * sign(c - c0) / (nband * T)
 };
 
 

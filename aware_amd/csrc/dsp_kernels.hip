@@ -461,14 +461,13 @@ __global__ __launch_bounds__(kThreads) void synth_kernel(SynthArgs a) {
 // bounds (multibit_embedder.py:157-160, :89-90) and optimiser state reset
 __global__ void embed_prepare_kernel(const float* __restrict__ c0, float* __restrict__ coef, float* __restrict__ lo,
                                      float* __restrict__ hi, float* __restrict__ mom, float* __restrict__ vel,
-                                     float* __restrict__ best, float ratio, size_t n) {
+                                     float* __restrict__ best, float* __restrict__ c0_keep, float ratio, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float c = c0[i];
-    float d = c * ratio;
     coef[i] = c;
-    lo[i] = fmaxf(c - d, 0.f);
-    hi[i] = c + d;
+    box_bounds(c, ratio, lo[i], hi[i]);
+    if (c0_keep) c0_keep[i] = c;
     mom[i] = 0.f;
     vel[i] = 0.f;
     best[i] = c;
@@ -564,9 +563,9 @@ void launch_synth(const SynthLaunch& L, hipStream_t st) {
 }
 
 void launch_embed_prepare(const float* c0, float* coef, float* lo, float* hi, float* mom, float* vel, float* best,
-                          float ratio, size_t n, hipStream_t st) {
+                          float* c0_keep, float ratio, size_t n, hipStream_t st) {
     hipLaunchKernelGGL(embed_prepare_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c0, coef, lo, hi, mom,
-                       vel, best, ratio, n);
+                       vel, best, c0_keep, ratio, n);
 }
 
 void launch_oob_residual(const float* audio, const int* in_off, const unsigned long long* pmax, const int* pcount,

@@ -196,16 +196,16 @@ __global__ __launch_bounds__(kSThreads, MODE == AN_ADJ ? 3 : 4) void analysis_st
         const size_t row = (size_t)(f0 + t);
         // operands of the optimiser epilogue do not depend on the transform: request them first
         cf preP[5];
-        float preM[5], preV[5], preC[5], preL[5], preH[5], pre0[5];
+        float preM[5], preV[5], preC[5], pre0[5];
         if (MODE == AN_ADJ) {
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
                 const int f = lane + 64 * r - band_lo;
                 const size_t idx = row * kFS + (size_t)min(max(f, 0), kFS - 1);       // clamped, masked at use
                 preP[r] = a.phasor[idx];
-                if (a.do_step) { preM[r] = a.mom[idx]; preV[r] = a.vel[idx]; preC[r] = a.coef[idx]; preL[r] = a.lo[idx]; preH[r] = a.hi[idx]; }
-                else { preM[r] = preV[r] = preL[r] = preH[r] = 0.f; preC[r] = L1 ? a.coef[idx] : 0.f; }
-                pre0[r] = L1 ? a.c0[idx] : 0.f;
+                if (a.do_step) { preM[r] = a.mom[idx]; preV[r] = a.vel[idx]; preC[r] = a.coef[idx]; }
+                else { preM[r] = preV[r] = 0.f; preC[r] = L1 ? a.coef[idx] : 0.f; }
+                pre0[r] = (a.do_step || L1) ? a.c0[idx] : 0.f;     // the box [lo, hi] is a function of c0: one operand, not two
             }
         }
         cf v[8];
@@ -217,10 +217,10 @@ __global__ __launch_bounds__(kSThreads, MODE == AN_ADJ ? 3 : 4) void analysis_st
         // the next frame shares three quarters with this one: roll, and request its new quarter now
 #pragma unroll
         for (int r = 0; r < 6; ++r) raw[r] = raw[r + 2];
-        if (fr + 1 < nfr) {
-            raw[6] = load_half(kHop * (t + 1) + 768);
-            raw[7] = load_half(kHop * (t + 1) + 896);
-        }
+        // (unconditional: behind the last frame of the run the quarter is simply not used -- positions past the clip are
+        // reflected / masked by load_half like any other)
+        raw[6] = load_half(kHop * (t + 1) + 768);
+        raw[7] = load_half(kHop * (t + 1) + 896);
         fft512_wave_t<-1>(lane, v, tw1s, tw2s, s);
 
         // real-FFT split: X[k] needs Z[k] (own register) and Z[512-k] = lane (64-L)&63, register 7-r (lane 0: own 8-r)
@@ -256,7 +256,9 @@ __global__ __launch_bounds__(kSThreads, MODE == AN_ADJ ? 3 : 4) void analysis_st
                 if (a.do_step) {
                     // torch.optim.NAdam single-tensor step + clamp + best snapshot (multibit_embedder.py:112-122)
                     float mo = preM[r], ve = preV[r], p = preC[r];
-                    nadam_clamp_update(p, mo, ve, g, preL[r], preH[r], sc.x, sc.y, inv_bc2, a.hyp);
+                    float blo, bhi;
+                    box_bounds(pre0[r], a.box_ratio, blo, bhi);
+                    nadam_clamp_update(p, mo, ve, g, blo, bhi, sc.x, sc.y, inv_bc2, a.hyp);
                     a.mom[idx] = mo; a.vel[idx] = ve; a.coef[idx] = p;
                     if (improved) a.best[idx] = p;
                 }
@@ -331,18 +333,24 @@ __global__ __launch_bounds__(kSThreads, 4) void synth_stream_kernel(SynthArgs a)
     // the partner 512-k otherwise; loads are unconditional from a clamped index, the amplitude masks the rest
     float inA[8];
     cf inP[8];
+    unsigned fo[8];                          // lane-constant column of slot r (clamped) and whether it lies in the band
+    unsigned inband = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int k = lane + 64 * r;
+        const int f = ((k <= 256) ? k : 512 - k) - band_lo;
+        fo[r] = (unsigned)min(max(f, 0), kFS - 1);
+        if (f >= 0 && f < nband) inband |= 1u << r;
+    }
     auto load_band = [&](int t) {
         const size_t row = (size_t)(f0 + t);
         const float* A = a.amp + row * kFS;
         const cf* P = a.ph + row * kFS;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            const int k = lane + 64 * r;
-            const int f = ((k <= 256) ? k : 512 - k) - band_lo;
-            const int fc_ = min(max(f, 0), kFS - 1);
-            const float am = A[fc_];
-            inP[r] = P[fc_];
-            inA[r] = (f >= 0 && f < nband) ? am : 0.f;
+            const float am = A[fo[r]];
+            inP[r] = P[fo[r]];
+            inA[r] = ((inband >> r) & 1u) ? am : 0.f;
         }
     };
 
@@ -354,12 +362,10 @@ __global__ __launch_bounds__(kSThreads, 4) void synth_stream_kernel(SynthArgs a)
     float l1 = 0.f;                          // sum of |amp - c0| over the band bins of the frames this run owns
     if (t_lo <= T - 1) load_band(t_lo);
 
-#pragma unroll 1
-    for (int t = t_lo; t <= t_hi; ++t) {
-        const int i = t - 2;                                  // the hop block that frame t completes
-        const bool emit = i >= jb0 && i < jb1;
-        // epilogue operands that do not depend on the transform
-        float2 e0 = make_float2(0.f, 0.f), e1 = e0;
+    // operands of a block's epilogue that do not depend on the transform (requested before it)
+    auto epi_operands = [&](int i, bool emit, float2& e0, float2& e1) {
+        e0 = make_float2(0.f, 0.f);
+        e1 = e0;
         if (emit) {
             const float* src = (MODE == SY_FWD) ? add : y;
             if (src) {
@@ -367,38 +373,9 @@ __global__ __launch_bounds__(kSThreads, 4) void synth_stream_kernel(SynthArgs a)
                 e1 = *reinterpret_cast<const float2*>(src + kHop * i + 128 + 2 * lane);
             }
         }
-        float2 c[8];
-        if (t <= T - 1) {
-            if (MODE == SY_FWD && L1 && ((t >= jb0 && t < jb1) || (last && t == T - 1))) {
-                // own bins of the slots: k = lane + 64 r <= 256 (r < 4, and lane 0 of r = 4)
-                const float* C0 = a.c0 + (size_t)(f0 + t) * kFS;
-#pragma unroll
-                for (int r = 0; r < 5; ++r) {
-                    const int f = lane + 64 * r - band_lo;
-                    const float cv = C0[min(max(f, 0), kFS - 1)];
-                    if (f >= 0 && f < nband && (r < 4 || lane == 0)) l1 += fabsf(inA[r] - cv);
-                }
-            }
-            cf v[8];
-            // irfft merge with one of the two inputs known to be zero (band inside bins 1..256):
-            //   k < 256:  Z[k] = X[k] * (1 + i conj W^k)/2        k >= 256:  Z[k] = conj(X[512-k]) * (1 - i conj W^k)/2
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const cf mc = mcs[lane + 64 * r];
-                const float xr = inA[r] * inP[r].x, xi = (r < 4) ? inA[r] * inP[r].y : -(inA[r] * inP[r].y);
-                v[r] = mk(xr * mc.x - xi * mc.y, xr * mc.y + xi * mc.x);
-            }
-            if (t + 1 <= min(t_hi, T - 1)) load_band(t + 1);
-            fft512_wave_t<1>(lane, v, tw1s, tw2s, s);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const float2 w = wins[lane + 64 * r];
-                c[r] = make_float2(v[r].x * w.x, v[r].y * w.y);
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) c[r] = make_float2(0.f, 0.f);
-        }
+    };
+    // overlap-add of one frame's windowed samples c[] and the epilogue of the hop block it completes
+    auto ola_emit = [&](int i, bool emit, const float2 (&c)[8], const float2 e0, const float2 e1) {
         // overlap-add in registers: quarter q of the frame = registers 2q, 2q+1; frames arrive in ascending order
         const float2 o0 = make_float2(acc[0].x + c[0].x, acc[0].y + c[0].y);
         const float2 o1 = make_float2(acc[1].x + c[1].x, acc[1].y + c[1].y);
@@ -462,6 +439,56 @@ __global__ __launch_bounds__(kSThreads, 4) void synth_stream_kernel(SynthArgs a)
                 }
             }
         }
+    };
+
+    const int t_fft = min(t_hi, T - 1);      // frames t_lo..t_fft exist; t_fft+1..t_hi only flush the accumulator
+#pragma unroll 1
+    for (int t = t_lo; t <= t_fft; ++t) {
+        const int i = t - 2;                                  // the hop block that frame t completes
+        const bool emit = i >= jb0 && i < jb1;
+        float2 e0, e1;
+        epi_operands(i, emit, e0, e1);
+        float2 c[8];
+        {
+            if (MODE == SY_FWD && L1 && ((t >= jb0 && t < jb1) || (last && t == T - 1))) {
+                // own bins of the slots: k = lane + 64 r <= 256 (r < 4, and lane 0 of r = 4)
+                const float* C0 = a.c0 + (size_t)(f0 + t) * kFS;
+#pragma unroll
+                for (int r = 0; r < 5; ++r) {
+                    const int f = lane + 64 * r - band_lo;
+                    const float cv = C0[min(max(f, 0), kFS - 1)];
+                    if (f >= 0 && f < nband && (r < 4 || lane == 0)) l1 += fabsf(inA[r] - cv);
+                }
+            }
+            cf v[8];
+            // irfft merge with one of the two inputs known to be zero (band inside bins 1..256):
+            //   k < 256:  Z[k] = X[k] * (1 + i conj W^k)/2        k >= 256:  Z[k] = conj(X[512-k]) * (1 - i conj W^k)/2
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const cf mc = mcs[lane + 64 * r];
+                const float xr = inA[r] * inP[r].x, xi = (r < 4) ? inA[r] * inP[r].y : -(inA[r] * inP[r].y);
+                v[r] = mk(xr * mc.x - xi * mc.y, xr * mc.y + xi * mc.x);
+            }
+            load_band(min(t + 1, T - 1));           // unconditional (clamped): no register copies around a branch
+            fft512_wave_t<1>(lane, v, tw1s, tw2s, s);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float2 w = wins[lane + 64 * r];
+                c[r] = make_float2(v[r].x * w.x, v[r].y * w.y);
+            }
+        }
+        ola_emit(i, emit, c, e0, e1);
+    }
+#pragma unroll 1
+    for (int t = t_fft + 1; t <= t_hi; ++t) {
+        const int i = t - 2;
+        const bool emit = i >= jb0 && i < jb1;
+        float2 e0, e1;
+        epi_operands(i, emit, e0, e1);
+        float2 c[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) c[r] = make_float2(0.f, 0.f);
+        ola_emit(i, emit, c, e0, e1);
     }
     if (MODE == SY_FWD) {
         if (a.pmax) {
@@ -511,7 +538,7 @@ void launch_analysis_stream(const AnalysisLaunch& L, hipStream_t st) {
     a.grad_out = L.grad_out; a.do_step = L.do_step;
     a.hyp = make_float4(L.hyp[0], L.hyp[1], L.hyp[2], L.hyp[3]);
     a.gpad = L.gpad; a.write_pad = L.write_pad;
-    a.c0 = L.c0; a.l1_weight = L.l1_weight;
+    a.c0 = L.c0; a.box_ratio = L.box_ratio; a.l1_weight = L.l1_weight;
     // frames per wave: long runs re-use three quarters of every frame from registers; short runs fill the chip when
     // the batch is small (a run start costs 8 loads per lane, every further frame 2)
     int R = 4;
@@ -520,7 +547,7 @@ void launch_analysis_stream(const AnalysisLaunch& L, hipStream_t st) {
     }
     const int runs = (L.max_frames + R - 1) / R;
     const dim3 grid((unsigned)((runs + kSW - 1) / kSW), (unsigned)L.B, 1);
-    if (L.adjoint && a.c0) hipLaunchKernelGGL((analysis_stream_kernel<AN_ADJ, true>), grid, dim3(kSThreads), 0, st, a, R);
+    if (L.adjoint && a.l1_weight != 0.f) hipLaunchKernelGGL((analysis_stream_kernel<AN_ADJ, true>), grid, dim3(kSThreads), 0, st, a, R);
     else if (L.adjoint) hipLaunchKernelGGL((analysis_stream_kernel<AN_ADJ, false>), grid, dim3(kSThreads), 0, st, a, R);
     else hipLaunchKernelGGL((analysis_stream_kernel<AN_NORM, false>), grid, dim3(kSThreads), 0, st, a, R);
 }

@@ -41,8 +41,9 @@ struct AnalysisLaunch {
     int stream = 0;
     const float* gpad = nullptr;      // stream + adjoint: reflect-pad parts written by the streaming synthesis adjoint
     int write_pad = 1;                // stream, forward: write the zero tail of the mag / unit rows
-    const float* c0 = nullptr;        // stream + adjoint: L1 term on the coefficients (loss push_extremes + L1)
-    float l1_weight = 0.f;
+    const float* c0 = nullptr;        // stream + adjoint: original coefficients (the box is recomputed from them)
+    float box_ratio = 0.f;            // 10^(-tolerance_db / 20)
+    float l1_weight = 0.f;            // != 0: L1 term on the coefficients (loss push_extremes + L1)
 };
 struct SynthLaunch {
     PlanDev plan;
@@ -78,7 +79,7 @@ void launch_synth_stream(const SynthLaunch& L, hipStream_t st);
 void launch_l1_reduce(const double* pl1, const int* pcount, int pstride, const int* frame_off, int nband, float weight,
                       float* l1term, int B, hipStream_t st);
 void launch_embed_prepare(const float* c0, float* coef, float* lo, float* hi, float* mom, float* vel, float* best,
-                          float ratio, size_t n, hipStream_t st);
+                          float* c0_keep, float ratio, size_t n, hipStream_t st);
 void launch_oob_residual(const float* audio, const int* in_off, const unsigned long long* pmax, const int* pcount,
                          int pstride, const float* band, const int* frame_off, float* oob, int B, int max_frames,
                          hipStream_t st);
