@@ -168,10 +168,12 @@ extern "C" int aware_batch_create(aware_batch** out, int B, const int* n_samples
     b->pc_in.resize(B);
     b->pc_syn.resize(B);
     int acc = 0, max_pc = 1;
-    // run length of the synthesis kernels (one wave of the streaming kernels per run): the longest of 16 / 8 / 4 hop
-    // blocks that still gives ~12 waves per CU; a run of r blocks transforms r + 3 frames, so short runs cost more
+    // run length of the synthesis kernels (one wave of the streaming kernels per run): the longest of 16 / 12 / 8 / 6 / 4
+    // hop blocks that still gives ~16 waves per CU; a run of r blocks transforms r + 3 frames, so short runs cost more
     // arithmetic and are only worth it while the chip would otherwise idle
-    for (int rb : {16, 8, 4}) {
+    // (measured, 3 s clips, us synthesis / adjoint: B = 256: 16 66/66, 12 65/64, 8 77/75; B = 128: 12 43/47, 8 40/42, 6 39/42,
+    // 4 51/52; B = 64: 8 31/30, 6 28/28, 4 28/28)
+    for (int rb : {16, 12, 8, 6, 4}) {
         long runs = 0;
         for (int i = 0; i < B; ++i) runs += (n_samples[i] / kHop + rb - 1) / rb;
         // the staged adjoint folds the reflect pads inside the first / last segment: keep those at >= 3 blocks
@@ -182,7 +184,7 @@ extern "C" int aware_batch_create(aware_batch** out, int B, const int* n_samples
         }
         if (!ok) continue;
         b->synth_run = rb;
-        if (runs >= 3072) break;
+        if (runs >= 4096) break;
     }
     b->frame_off[0] = 0;
     b->pool_off[0] = 0;

@@ -539,12 +539,16 @@ void launch_analysis_stream(const AnalysisLaunch& L, hipStream_t st) {
     a.hyp = make_float4(L.hyp[0], L.hyp[1], L.hyp[2], L.hyp[3]);
     a.gpad = L.gpad; a.write_pad = L.write_pad;
     a.c0 = L.c0; a.box_ratio = L.box_ratio; a.l1_weight = L.l1_weight;
-    // frames per wave: long runs re-use three quarters of every frame from registers; short runs fill the chip when
-    // the batch is small (a run start costs 8 loads per lane, every further frame 2)
+    // Frames per wave (run length R).  A run start costs 8 loads per lane, every further frame 2, so long runs are cheaper
+    // per frame; but the chip wants ~16 waves per CU, and a workgroup whose last waves have no run idles their slots.
+    // Measured on 3 s clips (us, analysis / adjoint): B = 256: R = 8 75/144, 12 67/118, 16 69/136; B = 128: R = 4 40/84,
+    // 8 38/79, 12 43/92; B = 64: R = 4 25/43, 8 32/59.  Rule: the longest R in [4, 16] that still gives 4096 waves, then
+    // the nearest shorter R whose run count per clip is a multiple of the 4 waves of a workgroup.
     int R = 4;
-    for (int cand : {16, 8, 4}) {
-        if ((long)L.B * ((L.max_frames + cand - 1) / cand) >= 5120) { R = cand; break; }
-    }
+    for (int cand = 16; cand >= 4; --cand)
+        if ((long)L.B * ((L.max_frames + cand - 1) / cand) >= 4096) { R = cand; break; }
+    for (int cand = R; cand >= 4 && cand >= R - 3; --cand)
+        if (((L.max_frames + cand - 1) / cand) % kSW == 0) { R = cand; break; }
     const int runs = (L.max_frames + R - 1) / R;
     const dim3 grid((unsigned)((runs + kSW - 1) / kSW), (unsigned)L.B, 1);
     if (L.adjoint && a.l1_weight != 0.f) hipLaunchKernelGGL((analysis_stream_kernel<AN_ADJ, true>), grid, dim3(kSThreads), 0, st, a, R);
