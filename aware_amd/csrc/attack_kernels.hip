@@ -72,28 +72,34 @@ __global__ __launch_bounds__(256) void upfirdn_kernel(const float* __restrict__ 
     }
 }
 
-// Direct-form-II-transposed IIR in float64, one thread per clip (the recurrence is
-// sequential in time; clips are the parallel dimension).  mode 0: lfilter with zero
-// state.  mode 1: filtfilt (odd extension by 3*ncoef samples, steady-state initial
-// conditions zi*x0, forward then backward); needs scratch[B][maxlen + 6*ncoef] doubles.
+// Direct-form-II-transposed IIR in float64 (scipy lfilter / filtfilt), one workgroup per clip, parallel in time.
+// The recurrence is linear, so a clip is cut into kIirChunks chunks of L samples, one per thread:
+//   pass A  every thread runs the recurrence over its chunk from a ZERO state (thread 0: from the true initial state)
+//           and keeps only the end state v[c]; meanwhile a fifth wave runs the zero-input recurrence from the unit
+//           states for L steps, which gives the L-step state transition matrix M;
+//   pass B  one wave chains the true chunk-start states z0[c+1] = M z0[c] + v[c] (lane k owns row k of M);
+//   pass C  every thread runs the same recurrence again over its chunk from its true start state and stores y.
+// The samples a thread emits are those of the sequential algorithm started from a state that differs from the
+// sequential one by the rounding of pass B (relative 1e-16): far below the float32 result of the attacks.
+//   mode 0: lfilter with zero state (LowPassFilter / HighPassFilter, attacks.py:400-455).
+//   mode 1: filtfilt (RandomBandstop, attacks.py:324-356): odd extension by 3*ncoef samples, steady-state initial
+//           conditions zi*x0, forward then backward; needs scratch[B][maxlen + 6*ncoef] doubles.
 constexpr int kMaxCoef = 12;
-// NC = number of coefficients (filter order + 1), compile-time so that the state lives in
-// registers; samples are fetched 16 at a time so that the load latency is paid once per 16
-// steps of the recurrence instead of once per step.
+constexpr int kIirChunks = 256;                  // worker threads (= chunks) per clip; + one wave for the matrix
 template <int NC>
-__global__ __launch_bounds__(64) void iir_kernel(const float* __restrict__ in, const int* __restrict__ off,
-                                                  const int* __restrict__ len, void* __restrict__ outv, int out_f64,
-                                                  const double* __restrict__ bc, const double* __restrict__ ac,
-                                                  const double* __restrict__ zic, int mode,
-                                                  double* __restrict__ scratch, int sstride, int B) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    constexpr int NS = NC - 1;
+__global__ __launch_bounds__(kIirChunks + 64) void iir_kernel(const float* __restrict__ in, const int* __restrict__ off,
+                                                              const int* __restrict__ len, void* __restrict__ outv,
+                                                              int out_f64, const double* __restrict__ bc,
+                                                              const double* __restrict__ ac, const double* __restrict__ zic,
+                                                              int mode, double* __restrict__ scratch, int sstride) {
+    constexpr int NS = NC - 1, NT = kIirChunks, CH = 16;
+    __shared__ double Vs[NT][NS];                // pass A: zero-state end states; after pass B: true start states
+    __shared__ double Ms[NS][NS];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const bool matrix_wave = tid >= NT;
     double bb[NC], aa[NC], z[NS];
 #pragma unroll
     for (int k = 0; k < NC; ++k) { bb[k] = bc[(size_t)b * NC + k]; aa[k] = ac[(size_t)b * NC + k]; }
-#pragma unroll
-    for (int k = 0; k < NS; ++k) z[k] = 0.0;
     const int n = len[b];
     const float* x = in + off[b];
     double* od = reinterpret_cast<double*>(outv) + off[b];
@@ -105,67 +111,108 @@ __global__ __launch_bounds__(64) void iir_kernel(const float* __restrict__ in, c
         z[NS - 1] = bb[NS] * xi - aa[NS] * yi;
         return yi;
     };
-    constexpr int CH = 16;
+    const int edge = mode ? 3 * NC : 0;
+    const int cnt = n + 2 * edge;                              // samples the recurrence runs over
+    const int L = CH * ((cnt + CH * NT - 1) / (CH * NT));     // chunk length, a multiple of CH
+    const int nch = (cnt + L - 1) / L;
+    double* s = scratch + (size_t)b * sstride;
+
+    if (matrix_wave) {
+        // column j of M: the state after L zero-input steps from the unit state e_j
+        const int j = lane < NS ? lane : NS - 1;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) z[k] = k == j ? 1.0 : 0.0;
+        for (int i = 0; i < L; ++i) step(0.0);
+        if (lane < NS) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) Ms[k][j] = z[k];
+        }
+    }
+    if (mode && !matrix_wave) {
+        // odd extension (scipy filtfilt padtype='odd', padlen = 3*max(len(a), len(b)))
+        const double x0 = (double)x[0], xl = (double)x[n - 1];
+        for (int i = tid; i < edge; i += NT) {
+            s[i] = 2.0 * x0 - (double)x[edge - i];
+            s[edge + n + i] = 2.0 * xl - (double)x[n - 2 - i];
+        }
+        for (int i = tid; i < n; i += NT) s[edge + i] = (double)x[i];
+    }
+    __syncthreads();
+
+    // one pass of the recurrence over elements [0, cnt) of a sequence given by ld(j) / st(j, y), from the state zinit
+    auto scan = [&](auto ld, auto st, const double (&zinit)[NS]) {
+        const int j0 = tid * L;
+        const int m = matrix_wave ? 0 : min(max(cnt - j0, 0), L);
+        if (!matrix_wave) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) z[k] = tid == 0 ? zinit[k] : 0.0;
+            int i = 0;
+            for (; i + CH <= m; i += CH) {
+                double xb[CH];
+#pragma unroll
+                for (int q = 0; q < CH; ++q) xb[q] = ld(j0 + i + q);
+#pragma unroll
+                for (int q = 0; q < CH; ++q) step(xb[q]);
+            }
+            for (; i < m; ++i) step(ld(j0 + i));
+#pragma unroll
+            for (int k = 0; k < NS; ++k) Vs[tid][k] = z[k];
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int k = lane < NS ? lane : NS - 1;
+            double mrow[NS];
+#pragma unroll
+            for (int q = 0; q < NS; ++q) mrow[q] = Ms[k][q];
+            double cur = Vs[0][k];                               // thread 0 started from the true state
+            for (int c = 1; c < nch; ++c) {
+                double nxt = Vs[c][k];
+                if (lane < NS) Vs[c][k] = cur;
+                const unsigned lo = (unsigned)__double_as_longlong(cur), hi = (unsigned)(__double_as_longlong(cur) >> 32);
+#pragma unroll
+                for (int q = 0; q < NS; ++q) {
+                    const unsigned ql = __builtin_amdgcn_readlane(lo, q), qh = __builtin_amdgcn_readlane(hi, q);
+                    nxt += mrow[q] * __longlong_as_double((long long)(((unsigned long long)qh << 32) | ql));
+                }
+                cur = nxt;
+            }
+        }
+        __syncthreads();
+        if (!matrix_wave && m > 0) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) z[k] = tid == 0 ? zinit[k] : Vs[tid][k];
+            int i = 0;
+            for (; i + CH <= m; i += CH) {
+                double xb[CH];
+#pragma unroll
+                for (int q = 0; q < CH; ++q) xb[q] = ld(j0 + i + q);
+#pragma unroll
+                for (int q = 0; q < CH; ++q) xb[q] = step(xb[q]);
+#pragma unroll
+                for (int q = 0; q < CH; ++q) st(j0 + i + q, xb[q]);
+            }
+            for (; i < m; ++i) st(j0 + i, step(ld(j0 + i)));
+        }
+        __syncthreads();
+    };
+
+    double zinit[NS];
     if (mode == 0) {
-        int i = 0;
-        for (; i + CH <= n; i += CH) {
-            float xb[CH];
-            double yb[CH];
 #pragma unroll
-            for (int j = 0; j < CH; ++j) xb[j] = x[i + j];
-#pragma unroll
-            for (int j = 0; j < CH; ++j) yb[j] = step((double)xb[j]);
-#pragma unroll
-            for (int j = 0; j < CH; ++j) { if (out_f64) od[i + j] = yb[j]; else of[i + j] = (float)yb[j]; }
-        }
-        for (; i < n; ++i) {
-            const double yi = step((double)x[i]);
-            if (out_f64) od[i] = yi; else of[i] = (float)yi;
-        }
+        for (int k = 0; k < NS; ++k) zinit[k] = 0.0;
+        scan([&](int j) { return (double)x[j]; },
+             [&](int j, double y) { if (out_f64) od[j] = y; else of[j] = (float)y; }, zinit);
         return;
     }
-    const int edge = 3 * NC;
-    double* s = scratch + (size_t)b * sstride;
-    const int ne = n + 2 * edge;
-    // odd extension (scipy filtfilt padtype='odd', padlen = 3*max(len(a), len(b)))
-    const double x0 = (double)x[0], xl = (double)x[n - 1];
-    for (int i = 0; i < edge; ++i) s[i] = 2.0 * x0 - (double)x[edge - i];
-    for (int i = 0; i < n; ++i) s[edge + i] = (double)x[i];
-    for (int i = 0; i < edge; ++i) s[edge + n + i] = 2.0 * xl - (double)x[n - 2 - i];
-    // forward
+    const double s0 = s[0];
 #pragma unroll
-    for (int k = 0; k < NS; ++k) z[k] = zic[(size_t)b * NS + k] * s[0];
-    {
-        int i = 0;
-        for (; i + CH <= ne; i += CH) {
-            double xb[CH];
+    for (int k = 0; k < NS; ++k) zinit[k] = zic[(size_t)b * NS + k] * s0;
+    scan([&](int j) { return s[j]; }, [&](int j, double y) { s[j] = y; }, zinit);            // forward
+    const double y0 = s[cnt - 1];
 #pragma unroll
-            for (int j = 0; j < CH; ++j) xb[j] = s[i + j];
-#pragma unroll
-            for (int j = 0; j < CH; ++j) xb[j] = step(xb[j]);
-#pragma unroll
-            for (int j = 0; j < CH; ++j) s[i + j] = xb[j];
-        }
-        for (; i < ne; ++i) s[i] = step(s[i]);
-    }
-    // backward
-    const double y0 = s[ne - 1];
-#pragma unroll
-    for (int k = 0; k < NS; ++k) z[k] = zic[(size_t)b * NS + k] * y0;
-    {
-        int i = ne - 1;
-        for (; i - CH + 1 >= 0; i -= CH) {
-            double xb[CH];
-#pragma unroll
-            for (int j = 0; j < CH; ++j) xb[j] = s[i - j];
-#pragma unroll
-            for (int j = 0; j < CH; ++j) xb[j] = step(xb[j]);
-#pragma unroll
-            for (int j = 0; j < CH; ++j) s[i - j] = xb[j];
-        }
-        for (; i >= 0; --i) s[i] = step(s[i]);
-    }
-    for (int i = 0; i < n; ++i) {
+    for (int k = 0; k < NS; ++k) zinit[k] = zic[(size_t)b * NS + k] * y0;
+    scan([&](int j) { return s[cnt - 1 - j]; }, [&](int j, double y) { s[cnt - 1 - j] = y; }, zinit);   // backward
+    for (int i = tid; i < n; i += NT + 64) {
         if (out_f64) od[i] = s[edge + i]; else of[i] = (float)s[edge + i];
     }
 }
@@ -290,8 +337,8 @@ void launch_iir_full(const float* in, const int* off, const int* len, void* out,
                      const double* a, const double* zi, int ncoef, int mode, double* scratch, int sstride, int B,
                      hipStream_t st) {
 #define IIR(NC_)                                                                                                       \
-    hipLaunchKernelGGL(iir_kernel<NC_>, dim3((B + 63) / 64), dim3(64), 0, st, in, off, len, out, out_f64, b, a, zi, mode, \
-                       scratch, sstride, B)
+    hipLaunchKernelGGL(iir_kernel<NC_>, dim3(B), dim3(kIirChunks + 64), 0, st, in, off, len, out, out_f64, b, a, zi, mode, \
+                       scratch, sstride)
     switch (ncoef) {
         case 2: IIR(2); break; case 3: IIR(3); break; case 4: IIR(4); break; case 5: IIR(5); break;
         case 6: IIR(6); break; case 7: IIR(7); break; case 8: IIR(8); break; case 9: IIR(9); break;

@@ -115,7 +115,11 @@ __device__ __forceinline__ void x3_tile_gemm(const float* __restrict__ A, int ld
     constexpr int BUF = 2 * KSS;          // one K tile (BK = 64)
     constexpr int NCH = (RG * 256 + NT - 1) / NT;     // 8-float chunks of the A tile per thread
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // wave-uniform values are forced into SGPRs so that every global load is `saddr + 32-bit voffset` (two VGPRs less
+    // per pointer than 64-bit VGPR addresses: the loop runs at the 128-VGPR limit of four waves per SIMD)
+    bm = __builtin_amdgcn_readfirstlane(bm);
+    bn = __builtin_amdgcn_readfirstlane(bn);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, kg = lane >> 4;
     const int srow = tid >> 3, sc = tid & 7;          // chunk i of this thread: row srow + (NT/8)*i, k = 8*sc
     unsigned rb[2];
@@ -124,11 +128,11 @@ __device__ __forceinline__ void x3_tile_gemm(const float* __restrict__ A, int ld
 
     const int KS2 = K >> 5;
     const int nkt = K >> 6;
-    const u32x4* bp = Bpk + ((size_t)((bn >> 4) + wave * NTW) * KS2) * 192 + lane;
-    const float* ap = A + (size_t)bm * lda + sc * 8;
-    int roff[NCH];
+    const u32x4* bp = Bpk + ((size_t)((bn >> 4) + wave * NTW) * KS2) * 192;          // uniform; + lane per thread
+    const float* ap = A + (size_t)bm * lda;                                          // uniform
+    unsigned roff[NCH];
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) roff[i] = min(srow + (NT / 8) * i, row_limit - 1) * lda;
+    for (int i = 0; i < NCH; ++i) roff[i] = (unsigned)(min(srow + (NT / 8) * i, row_limit - 1) * lda + sc * 8);
 
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -139,9 +143,9 @@ __device__ __forceinline__ void x3_tile_gemm(const float* __restrict__ A, int ld
     auto chunk_ok = [&](int i) { return (RG * 256) % NT == 0 || tid + NT * i < RG * 256; };
     auto gload_c = [&](int i, int kt) {
         if (chunk_ok(i)) {
-            const float* p = ap + roff[i] + kt * 64;
-            ra[i][0] = *reinterpret_cast<const float4*>(p);
-            ra[i][1] = *reinterpret_cast<const float4*>(p + 4);
+            const float* p = ap + kt * 64;
+            ra[i][0] = *reinterpret_cast<const float4*>(p + roff[i]);
+            ra[i][1] = *reinterpret_cast<const float4*>(p + roff[i] + 4);
         }
     };
     auto split_store_c = [&](int i, unsigned boff) {
@@ -164,17 +168,29 @@ __device__ __forceinline__ void x3_tile_gemm(const float* __restrict__ A, int ld
 #pragma unroll
         for (int n = 0; n < NTW; ++n)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bq[set][p][n] = bp[((size_t)n * KS2 + ks2) * 192 + p * 64];
+            for (int p = 0; p < 3; ++p) bq[set][p][n] = (bp + ((size_t)n * KS2 + ks2) * 192 + p * 64)[(unsigned)lane];
     };
     auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    bf16x8 af[2][3][MH];
-    auto read_frags = [&](int set, unsigned off) {     // off: buffer + rb[K32 step] + half * MH * FRAG
+    // A fragments are single-buffered and refilled on a rolling schedule: the six partial products of a quarter go
+    // smallest first -- (a2,b0) (a1,b1) (a0,b2) (a1,b0) (a0,b1) (a0,b0) -- so plane 2 is free after the first product,
+    // plane 1 after the fourth and plane 0 after the sixth; the next quarter's fragments are read into each plane as soon
+    // as it is free, 6-15 MFMAs before their first use.  (Double-buffering all three planes needs 72 VGPRs and pushed
+    // the kernel past the 128-VGPR budget of four waves per SIMD: the compiler then issued each read right before its use.)
+    bf16x8 af[3][MH];
+    auto read_plane = [&](int p, unsigned off) {       // off: buffer + rb[K32 step] + half * MH * FRAG
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int m = 0; m < MH; ++m)
-                af[set][p][m] = *reinterpret_cast<const bf16x8*>(lds + off + p * PLANE + m * FRAG);
+        for (int m = 0; m < MH; ++m) af[p][m] = *reinterpret_cast<const bf16x8*>(lds + off + p * PLANE + m * FRAG);
     };
+    auto product = [&](int pa, int pb, int t, int hf) {
+#pragma unroll
+        for (int m = 0; m < MH; ++m)
+#pragma unroll
+            for (int n = 0; n < NTW; ++n)
+                acc[hf * MH + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[pa][m], __builtin_bit_cast(bf16x8, bq[t][pb][n]),
+                                                                              acc[hf * MH + m][n], 0, 0, 0);
+    };
+    // the issue order is pinned (0x008 = MFMA, 0x100 = LDS read): left alone, the scheduler bunches the reads
+#define X3_PIN(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 
 #pragma unroll
     for (int i = 0; i < NCH; ++i) gload_c(i, 0);
@@ -184,7 +200,8 @@ __device__ __forceinline__ void x3_tile_gemm(const float* __restrict__ A, int ld
 #pragma unroll
     for (int i = 0; i < NCH; ++i) gload_c(i, nkt > 1 ? 1 : 0);
     lds_barrier();
-    read_frags(0, rb[0]);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) read_plane(p, rb[0]);
     for (int kt = 0; kt < nkt; ++kt) {
         const unsigned cur = (kt & 1) * BUF, nxt = BUF - cur;
         const int ktn = kt + 2 < nkt ? kt + 2 : nkt - 1;
@@ -196,27 +213,26 @@ __device__ __forceinline__ void x3_tile_gemm(const float* __restrict__ A, int ld
                 split_store_c(q, nxt);
                 gload_c(q, ktn);
             }
-            if (q < 3) {
-                read_frags((q + 1) & 1, cur + rb[(q + 1) >> 1] + ((q + 1) & 1) * MH * FRAG);
-            } else {
-                lds_barrier();               // tile kt+1 is complete; every wave has read all of tile kt
-                read_frags(0, nxt + rb[0]);
-            }
-            const int cs = q & 1;
-            // the six partial products, smallest first: (a2,b0) (a1,b1) (a0,b2) (a1,b0) (a0,b1) (a0,b0)
-#pragma unroll
-            for (int term = 0; term < 6; ++term) {
-                const int pa = term == 0 ? 2 : (term == 1 || term == 3) ? 1 : 0;
-                const int pb = term == 2 ? 2 : (term == 1 || term == 4) ? 1 : 0;
-#pragma unroll
-                for (int m = 0; m < MH; ++m)
-#pragma unroll
-                    for (int n = 0; n < NTW; ++n)
-                        acc[hf * MH + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            af[cs][pa][m], __builtin_bit_cast(bf16x8, bq[t][pb][n]), acc[hf * MH + m][n], 0, 0, 0);
-            }
+            const unsigned noff = q < 3 ? cur + rb[(q + 1) >> 1] + ((q + 1) & 1) * MH * FRAG : nxt + rb[0];
+            product(2, 0, t, hf);
+            X3_PIN(0x008, MH * NTW);
+            if (q == 3) lds_barrier();       // tile kt+1 is complete; every wave has issued and finished its reads of tile kt
+            read_plane(2, noff);
+            X3_PIN(0x100, MH);
+            product(1, 1, t, hf);
+            product(0, 2, t, hf);
+            product(1, 0, t, hf);
+            X3_PIN(0x008, 3 * MH * NTW);
+            read_plane(1, noff);
+            X3_PIN(0x100, MH);
+            product(0, 1, t, hf);
+            product(0, 0, t, hf);
+            X3_PIN(0x008, 2 * MH * NTW);
+            read_plane(0, noff);
+            X3_PIN(0x100, MH);
         }
     }
+#undef X3_PIN
 }
 
 // (RG <= 3: two 8-wave workgroups per CU = four waves per SIMD need <= 128 VGPRs; RG = 4 does not fit that)
