@@ -67,6 +67,11 @@ struct aware_batch {
     int* d_mem = nullptr;
     int *d_frame_off = nullptr, *d_pool_off = nullptr, *d_in_off = nullptr, *d_in_len = nullptr, *d_out_off = nullptr,
         *d_out_len = nullptr, *d_pc_in = nullptr, *d_pc_syn = nullptr;
+    // streaming DSP kernels: one workgroup = kStreamWaves runs of one clip; flat tables (clip << 12 | workgroup within the
+    // clip) so that a ragged batch launches exactly the workgroups that have work
+    int an_run = 0, n_an_wg = 0, n_syn_wg = 0;
+    int *d_an_wg = nullptr, *d_syn_wg = nullptr;
+    std::vector<int> an_wg, syn_wg;
 };
 
 struct aware_detector {
@@ -216,7 +221,30 @@ extern "C" int aware_batch_create(aware_batch** out, int B, const int* n_samples
         if (b->T[i] / 2 != b->uniform_tp) b->uniform_tp = 0;
     b->NS = kHop * (b->NF - B);
     b->pstride = max_pc;
-    const size_t ints = (size_t)(B + 1) * 2 + (size_t)B * 6;
+    {
+        // frames per analysis run: the longest R in [4, 16] that still gives 4096 waves; for a uniform batch then the nearest
+        // shorter R whose run count per clip is a multiple of the waves of a workgroup (measurements: dsp_stream.hip)
+        auto total_runs = [&](int r) { long t = 0; for (int i = 0; i < B; ++i) t += (b->T[i] + r - 1) / r; return t; };
+        int R = 4;
+        for (int cand = 16; cand >= 4; --cand)
+            if (total_runs(cand) >= 4096) { R = cand; break; }
+        bool same = true;
+        for (int i = 1; i < B; ++i) same = same && b->T[i] == b->T[0];
+        if (same)
+            for (int cand = R; cand >= 4 && cand >= R - 3; --cand)
+                if (((b->T[0] + cand - 1) / cand) % kStreamWaves == 0) { R = cand; break; }
+        b->an_run = R;
+        if (B < (1 << 19) && b->max_frames / 4 < 4096 * kStreamWaves) {
+            for (int i = 0; i < B; ++i) {
+                const int ra = (b->T[i] + R - 1) / R, rs = std::max(1, (b->T[i] - 1 + b->synth_run - 1) / b->synth_run);
+                for (int w = 0; w < (ra + kStreamWaves - 1) / kStreamWaves; ++w) b->an_wg.push_back((i << 12) | w);
+                for (int w = 0; w < (rs + kStreamWaves - 1) / kStreamWaves; ++w) b->syn_wg.push_back((i << 12) | w);
+            }
+        }
+        b->n_an_wg = (int)b->an_wg.size();
+        b->n_syn_wg = (int)b->syn_wg.size();
+    }
+    const size_t ints = (size_t)(B + 1) * 2 + (size_t)B * 6 + b->an_wg.size() + b->syn_wg.size();
     HIPCHK(hipMalloc((void**)&b->d_mem, ints * sizeof(int)));
     int* d = b->d_mem;
     auto up = [&](int*& dst, const std::vector<int>& v) -> hipError_t {
@@ -232,6 +260,8 @@ extern "C" int aware_batch_create(aware_batch** out, int B, const int* n_samples
     HIPCHK(up(b->d_out_len, b->out_len));
     HIPCHK(up(b->d_pc_in, b->pc_in));
     HIPCHK(up(b->d_pc_syn, b->pc_syn));
+    if (b->n_an_wg) HIPCHK(up(b->d_an_wg, b->an_wg));
+    if (b->n_syn_wg) HIPCHK(up(b->d_syn_wg, b->syn_wg));
     *out = b;
     return AWARE_OK;
 }
@@ -295,7 +325,7 @@ extern "C" int aware_stft(const aware_plan* plan, const aware_batch* b, const fl
         LAUNCHCHK();
     }
     AnalysisLaunch L;
-    L.plan = plan->dev; L.frame_off = b->d_frame_off; L.B = b->B; L.max_frames = b->max_frames;
+    L.plan = plan->dev; L.frame_off = b->d_frame_off; L.B = b->B; L.max_frames = b->max_frames; L.run_frames = b->an_run; L.wg_tab = b->d_an_wg; L.n_wg = b->n_an_wg;
     L.sig = audio; L.sig_off = b->d_in_off; L.sig_len = b->d_in_len;
     L.pmax = normalize ? pmax : nullptr; L.pcount = b->d_pc_in; L.pstride = b->pstride;
     L.full = spec;
@@ -314,7 +344,7 @@ extern "C" int aware_stft_band(const aware_plan* plan, const aware_batch* b, con
         LAUNCHCHK();
     }
     AnalysisLaunch L;
-    L.plan = plan->dev; L.frame_off = b->d_frame_off; L.B = b->B; L.max_frames = b->max_frames;
+    L.plan = plan->dev; L.frame_off = b->d_frame_off; L.B = b->B; L.max_frames = b->max_frames; L.run_frames = b->an_run; L.wg_tab = b->d_an_wg; L.n_wg = b->n_an_wg;
     L.sig = audio; L.sig_off = b->d_in_off; L.sig_len = b->d_in_len;
     L.pmax = normalize ? pmax : nullptr; L.pcount = b->d_pc_in; L.pstride = b->pstride;
     L.mag = mag; L.unit = phasor; L.unit_default = 1.f;
@@ -329,7 +359,7 @@ extern "C" int aware_istft(const aware_plan* plan, const aware_batch* b, const v
     hipStream_t st = (hipStream_t)stream;
     unsigned long long* pmax = (unsigned long long*)scratch;
     SynthLaunch S;
-    S.plan = plan->dev; S.frame_off = b->d_frame_off; S.B = b->B; S.max_frames = b->max_frames; S.run_blocks = b->synth_run;
+    S.plan = plan->dev; S.frame_off = b->d_frame_off; S.B = b->B; S.max_frames = b->max_frames; S.run_blocks = b->synth_run; S.wg_tab = b->d_syn_wg; S.n_wg = b->n_syn_wg;
     S.full = spec; S.out = out; S.pmax = normalize ? pmax : nullptr; S.pstride = b->pstride;
     launch_synth(S, st);
     LAUNCHCHK();
@@ -350,7 +380,7 @@ extern "C" int aware_stft_bwd(const aware_plan* plan, const aware_batch* b, cons
     for (int i = 0; i < b->B; ++i)
         if (b->n[i] != b->out_len[i] || b->in_off[i] != b->out_off[i]) return AWARE_E_UNSUPPORTED;
     SynthLaunch S;
-    S.plan = plan->dev; S.frame_off = b->d_frame_off; S.B = b->B; S.max_frames = b->max_frames; S.run_blocks = b->synth_run;
+    S.plan = plan->dev; S.frame_off = b->d_frame_off; S.B = b->B; S.max_frames = b->max_frames; S.run_blocks = b->synth_run; S.wg_tab = b->d_syn_wg; S.n_wg = b->n_syn_wg;
     S.full = grad_spec; S.out = grad_audio; S.adjoint = 1; S.pstride = b->pstride;
     launch_synth(S, (hipStream_t)stream);
     LAUNCHCHK();
@@ -361,7 +391,7 @@ extern "C" int aware_istft_bwd(const aware_plan* plan, const aware_batch* b, con
                                void* stream) {
     if (!plan || !b || !grad_audio || !grad_spec) return AWARE_E_BADARG;
     AnalysisLaunch L;
-    L.plan = plan->dev; L.frame_off = b->d_frame_off; L.B = b->B; L.max_frames = b->max_frames;
+    L.plan = plan->dev; L.frame_off = b->d_frame_off; L.B = b->B; L.max_frames = b->max_frames; L.run_frames = b->an_run; L.wg_tab = b->d_an_wg; L.n_wg = b->n_an_wg;
     L.sig = grad_audio; L.sig_off = b->d_out_off; L.sig_len = b->d_out_len;
     L.pcount = b->d_pc_syn; L.pstride = b->pstride;
     L.full = grad_spec; L.adjoint = 1;
@@ -1038,7 +1068,7 @@ extern "C" int aware_embed_begin(aware_embed* e, const float* audio, const float
     launch_absmax_partials(audio, b->d_in_off, b->d_in_len, e->pmaxA, b->pstride, b->B, b->max_len, st);
     LAUNCHCHK();
     AnalysisLaunch L;
-    L.plan = e->plan->dev; L.frame_off = b->d_frame_off; L.B = b->B; L.max_frames = b->max_frames;
+    L.plan = e->plan->dev; L.frame_off = b->d_frame_off; L.B = b->B; L.max_frames = b->max_frames; L.run_frames = b->an_run; L.wg_tab = b->d_an_wg; L.n_wg = b->n_an_wg;
     L.sig = audio; L.sig_off = b->d_in_off; L.sig_len = b->d_in_len;
     L.pmax = e->pmaxA; L.pcount = b->d_pc_in; L.pstride = b->pstride;
     L.mag = e->mag; L.unit = e->P; L.unit_default = 1.f;
@@ -1046,7 +1076,7 @@ extern "C" int aware_embed_begin(aware_embed* e, const float* audio, const float
     LAUNCHCHK();
     // constant out-of-band part of every synthesis: x/m - istft(band of the original)
     SynthLaunch S;
-    S.plan = e->plan->dev; S.frame_off = b->d_frame_off; S.B = b->B; S.max_frames = b->max_frames; S.run_blocks = b->synth_run;
+    S.plan = e->plan->dev; S.frame_off = b->d_frame_off; S.B = b->B; S.max_frames = b->max_frames; S.run_blocks = b->synth_run; S.wg_tab = b->d_syn_wg; S.n_wg = b->n_syn_wg;
     S.amp = e->mag; S.ph = e->P; S.out = e->gy; S.pstride = b->pstride;
     run_synth(S, e->cfg.dsp_path, st);
     LAUNCHCHK();
@@ -1070,7 +1100,7 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
     const aware_detector* d = e->det;
     // :99-103  scatter + Assembler + ISTFT  (out-of-band part is the constant `oob`)
     SynthLaunch S;
-    S.plan = e->plan->dev; S.frame_off = b->d_frame_off; S.B = b->B; S.max_frames = b->max_frames; S.run_blocks = b->synth_run;
+    S.plan = e->plan->dev; S.frame_off = b->d_frame_off; S.B = b->B; S.max_frames = b->max_frames; S.run_blocks = b->synth_run; S.wg_tab = b->d_syn_wg; S.n_wg = b->n_syn_wg;
     S.amp = e->coef; S.ph = e->P; S.out = e->yraw; S.add = e->oob; S.pmax = e->pmaxY; S.pstride = b->pstride;
     S.c0 = e->pl1 ? e->c0 : nullptr; S.pl1 = e->pl1;
     const int dsp = e->cfg.dsp_path;
@@ -1082,7 +1112,7 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
     }
     // normalise x2 + STFT + |.| on the band (:104 zeroes the rest, so it is never computed)
     AnalysisLaunch L;
-    L.plan = e->plan->dev; L.frame_off = b->d_frame_off; L.B = b->B; L.max_frames = b->max_frames;
+    L.plan = e->plan->dev; L.frame_off = b->d_frame_off; L.B = b->B; L.max_frames = b->max_frames; L.run_frames = b->an_run; L.wg_tab = b->d_an_wg; L.n_wg = b->n_an_wg;
     L.sig = e->yraw; L.sig_off = b->d_out_off; L.sig_len = b->d_out_len;
     L.pmax = e->pmaxY; L.pcount = b->d_pc_syn; L.pstride = b->pstride; L.double_norm = 1;
     L.mag = e->mag; L.unit = e->U; L.unit_default = 0.f; L.write_pad = 0;
@@ -1101,14 +1131,14 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
     if (rc) return rc;
     // backward through |.|, STFT, reflect padding
     SynthLaunch SA;
-    SA.plan = e->plan->dev; SA.frame_off = b->d_frame_off; SA.B = b->B; SA.max_frames = b->max_frames; SA.run_blocks = b->synth_run;
+    SA.plan = e->plan->dev; SA.frame_off = b->d_frame_off; SA.B = b->B; SA.max_frames = b->max_frames; SA.run_blocks = b->synth_run; SA.wg_tab = b->d_syn_wg; SA.n_wg = b->n_syn_wg;
     SA.amp = e->gmag; SA.ph = e->U; SA.out = e->gy; SA.adjoint = 1; SA.yraw = e->yraw; SA.pmax_in = e->pmaxY;
     SA.pcount = b->d_pc_syn; SA.pdot = e->pdot; SA.pstride = b->pstride; SA.gpad = e->gpad;
     run_synth(SA, dsp, st);
     LAUNCHCHK(); PROF(K_SYNTH_ADJ);
     // backward through the normalisers, ISTFT and the assembler; :112-117 NAdam + clamp
     AnalysisLaunch LA;
-    LA.plan = e->plan->dev; LA.frame_off = b->d_frame_off; LA.B = b->B; LA.max_frames = b->max_frames;
+    LA.plan = e->plan->dev; LA.frame_off = b->d_frame_off; LA.B = b->B; LA.max_frames = b->max_frames; LA.run_frames = b->an_run; LA.wg_tab = b->d_an_wg; LA.n_wg = b->n_an_wg;
     LA.sig = e->gy; LA.sig_off = b->d_out_off; LA.sig_len = b->d_out_len;
     LA.pmax = e->pmaxY; LA.pcount = b->d_pc_syn; LA.pstride = b->pstride;
     LA.adjoint = 1; LA.yraw = e->yraw; LA.pdot = e->pdot; LA.phasor = e->P;
@@ -1198,7 +1228,7 @@ extern "C" int aware_embed_finish(aware_embed* e, const float* rescale, float* o
     hipStream_t st = (hipStream_t)stream;
     const aware_batch* b = e->b;
     SynthLaunch S;
-    S.plan = e->plan->dev; S.frame_off = b->d_frame_off; S.B = b->B; S.max_frames = b->max_frames; S.run_blocks = b->synth_run;
+    S.plan = e->plan->dev; S.frame_off = b->d_frame_off; S.B = b->B; S.max_frames = b->max_frames; S.run_blocks = b->synth_run; S.wg_tab = b->d_syn_wg; S.n_wg = b->n_syn_wg;
     S.amp = e->best; S.ph = e->P; S.out = e->yraw; S.add = e->oob; S.pmax = e->pmaxY; S.pstride = b->pstride;
     run_synth(S, e->cfg.dsp_path, st);
     LAUNCHCHK();

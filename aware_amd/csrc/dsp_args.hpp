@@ -45,6 +45,7 @@ enum { SY_FWD = 0, SY_ADJ = 1 };
 struct AnalysisArgs {
     PlanDev plan;
     const int* frame_off;             // [B+1]
+    const int* wg_tab;                // streaming kernels: [gridDim.x] clip << 12 | workgroup within the clip (null: 2-D grid)
     const float* sig;                 // signal base
     const int* sig_off;               // [B] float offset of clip b in `sig`
     const int* sig_len;               // [B] samples (reflect padding uses this length)
@@ -85,6 +86,7 @@ struct AnalysisArgs {
 struct SynthArgs {
     PlanDev plan;
     const int* frame_off;
+    const int* wg_tab;                // as in AnalysisArgs
     const float* amp;                 // [NF][kFS] real amplitude (coefficients or dL/dmag)
     const cf* ph;                     // [NF][kFS] unit phasor
     const cf* full;                   // [NF][520] full complex spectrum (SY_FWD only) or null

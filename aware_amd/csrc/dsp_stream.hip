@@ -31,7 +31,7 @@
 
 namespace aware {
 
-constexpr int kSW = 4;                 // waves per workgroup (they share only the read-only tables)
+constexpr int kSW = kStreamWaves;      // waves per workgroup (they share only the read-only tables)
 constexpr int kSThreads = 64 * kSW;
 
 // per-clip normaliser state from the per-run partial maxima, reduced by ONE wave (no barrier)
@@ -82,11 +82,12 @@ __global__ __launch_bounds__(kSThreads, MODE == AN_ADJ ? 3 : 4) void analysis_st
     for (int i = tid; i < 512; i += kSThreads) wins[i] = make_float2(a.plan.window[2 * i], a.plan.window[2 * i + 1]);
     __syncthreads();
 
-    const int b = blockIdx.y;
+    int b = blockIdx.y, wgx = blockIdx.x;
+    if (a.wg_tab) { const int e = a.wg_tab[blockIdx.x]; b = e >> 12; wgx = e & 4095; }
     const int f0 = a.frame_off[b];
     const int T = a.frame_off[b + 1] - f0;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int t0 = (blockIdx.x * kSW + wave) * run_frames;
+    const int t0 = (wgx * kSW + wave) * run_frames;
     if (t0 >= T) return;
     const int nfr = min(run_frames, T - t0);
     const int n = a.sig_len[b];
@@ -301,12 +302,13 @@ __global__ __launch_bounds__(kSThreads, 4) void synth_stream_kernel(SynthArgs a)
     }
     __syncthreads();
 
-    const int b = blockIdx.y;
+    int b = blockIdx.y, wgx = blockIdx.x;
+    if (a.wg_tab) { const int e = a.wg_tab[blockIdx.x]; b = e >> 12; wgx = e & 4095; }
     const int f0 = a.frame_off[b];
     const int T = a.frame_off[b + 1] - f0;
     const int nblk = T - 1;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int run = blockIdx.x * kSW + wave;
+    const int run = wgx * kSW + wave;
     int nseg, jb0, jb1;
     synth_segment(nblk, run, a.run_blocks, nseg, jb0, jb1);
     if (run >= nseg || T < 1) return;
@@ -544,13 +546,21 @@ void launch_analysis_stream(const AnalysisLaunch& L, hipStream_t st) {
     // Measured on 3 s clips (us, analysis / adjoint): B = 256: R = 8 75/144, 12 67/118, 16 69/136; B = 128: R = 4 40/84,
     // 8 38/79, 12 43/92; B = 64: R = 4 25/43, 8 32/59.  Rule: the longest R in [4, 16] that still gives 4096 waves, then
     // the nearest shorter R whose run count per clip is a multiple of the 4 waves of a workgroup.
+    // (a batch handle applies the rule to the sum over its clips and passes R with the flat workgroup table built for it)
     int R = 4;
-    for (int cand = 16; cand >= 4; --cand)
-        if ((long)L.B * ((L.max_frames + cand - 1) / cand) >= 4096) { R = cand; break; }
-    for (int cand = R; cand >= 4 && cand >= R - 3; --cand)
-        if (((L.max_frames + cand - 1) / cand) % kSW == 0) { R = cand; break; }
-    const int runs = (L.max_frames + R - 1) / R;
-    const dim3 grid((unsigned)((runs + kSW - 1) / kSW), (unsigned)L.B, 1);
+    dim3 grid;
+    if (L.run_frames >= 4 && L.run_frames <= 16 && L.wg_tab && L.n_wg > 0) {
+        R = L.run_frames;
+        a.wg_tab = L.wg_tab;
+        grid = dim3((unsigned)L.n_wg, 1, 1);
+    } else {
+        for (int cand = 16; cand >= 4; --cand)
+            if ((long)L.B * ((L.max_frames + cand - 1) / cand) >= 4096) { R = cand; break; }
+        for (int cand = R; cand >= 4 && cand >= R - 3; --cand)
+            if (((L.max_frames + cand - 1) / cand) % kSW == 0) { R = cand; break; }
+        const int runs = (L.max_frames + R - 1) / R;
+        grid = dim3((unsigned)((runs + kSW - 1) / kSW), (unsigned)L.B, 1);
+    }
     if (L.adjoint && a.l1_weight != 0.f) hipLaunchKernelGGL((analysis_stream_kernel<AN_ADJ, true>), grid, dim3(kSThreads), 0, st, a, R);
     else if (L.adjoint) hipLaunchKernelGGL((analysis_stream_kernel<AN_ADJ, false>), grid, dim3(kSThreads), 0, st, a, R);
     else hipLaunchKernelGGL((analysis_stream_kernel<AN_NORM, false>), grid, dim3(kSThreads), 0, st, a, R);
@@ -568,7 +578,11 @@ void launch_synth_stream(const SynthLaunch& L, hipStream_t st) {
     a.run_blocks = (L.run_blocks >= 1 && L.run_blocks <= kSynthBlocks) ? L.run_blocks : kSynthBlocks;
     int runs = (nblk + a.run_blocks - 1) / a.run_blocks;
     if (runs < 1) runs = 1;
-    const dim3 grid((unsigned)((runs + kSW - 1) / kSW), (unsigned)L.B, 1);
+    dim3 grid((unsigned)((runs + kSW - 1) / kSW), (unsigned)L.B, 1);
+    if (L.wg_tab && L.n_wg > 0 && a.run_blocks == L.run_blocks) {
+        a.wg_tab = L.wg_tab;
+        grid = dim3((unsigned)L.n_wg, 1, 1);
+    }
     if (L.adjoint) hipLaunchKernelGGL((synth_stream_kernel<SY_ADJ, false>), grid, dim3(kSThreads), 0, st, a);
     else if (a.pl1) hipLaunchKernelGGL((synth_stream_kernel<SY_FWD, true>), grid, dim3(kSThreads), 0, st, a);
     else hipLaunchKernelGGL((synth_stream_kernel<SY_FWD, false>), grid, dim3(kSThreads), 0, st, a);

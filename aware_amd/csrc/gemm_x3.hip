@@ -443,6 +443,16 @@ constexpr int kRaggedRG = 3;           // largest chunk, in 32-row groups
 // st0/st1/st2: forward (count, mean, M2) of the column; backward (unused, sum dU, sum dU*u) in-lane partial sums
 extern __shared__ __attribute__((aligned(16))) unsigned char x3_dyn_lds[];    // the ragged kernel's staging memory (dynamic LDS)
 
+template <class T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+    // a wave-uniform pointer to GLOBAL memory that arrived as a function argument: in VGPRs and in the generic address
+    // space (flat loads count on vmcnt AND lgkmcnt, so every wait in the K loop became a full drain of both).  Back to an
+    // SGPR pair, and through address space 1 so that the loads are global_load again.
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (T*)(__attribute__((address_space(1))) T*)(((unsigned long long)hi << 32) | lo);
+}
+
 // (not inlined: each tile height keeps its own register allocation -- inlined side by side the two K loops cost the
 // kernel 20-40 spilled VGPRs inside the loop)
 template <int RG, int EPI>
@@ -452,6 +462,14 @@ __device__ __attribute__((noinline)) void x3_ragged_chunk(const bool SINGLE, con
                                                 float* __restrict__ rstd_clip, const float* __restrict__ act, float& st0,
                                                 float& st1, float& st2) {
     unsigned char* lds = x3_dyn_lds;
+    // the arguments of a non-inlined function arrive in VGPRs; all of these are wave-uniform and go back to SGPRs (the K
+    // loop runs at the 128-VGPR limit: left in VGPRs they were spilled and reloaded inside it)
+    A = uniform_ptr(A); Bpk = uniform_ptr(Bpk); bias = uniform_ptr(bias); C = uniform_ptr(C);
+    rstd_clip = uniform_ptr(rstd_clip); act = uniform_ptr(act);
+    lda = __builtin_amdgcn_readfirstlane(lda); ldc = __builtin_amdgcn_readfirstlane(ldc);
+    N = __builtin_amdgcn_readfirstlane(N); K = __builtin_amdgcn_readfirstlane(K);
+    bm = __builtin_amdgcn_readfirstlane(bm); bn = __builtin_amdgcn_readfirstlane(bn);
+    rows = __builtin_amdgcn_readfirstlane(rows); store_rows = __builtin_amdgcn_readfirstlane(store_rows);
     // rows: valid rows of the chunk; store_rows (a multiple of 32, <= 32 RG): rows of the clip's allocation under this tile
     constexpr int MT = 2 * RG;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -595,6 +613,9 @@ __global__ __launch_bounds__(512, 4) void gemm_ragged_x3_kernel(const float* __r
         g0 += ng;
     }
     if (single) return;
+#ifdef X3_ABLATE_PASS2
+    return;
+#endif
     // ---- pass 2: this lane's column of every row, read back from the raw tile it wrote ----
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, kg = lane >> 4;

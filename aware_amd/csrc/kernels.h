@@ -8,10 +8,16 @@
 namespace aware {
 
 // ---- dsp_kernels.hip ------------------------------------------------------------------
+constexpr int kStreamWaves = 4;        // waves (= runs) per workgroup of the streaming DSP kernels
+
 struct AnalysisLaunch {
     PlanDev plan;
     const int* frame_off = nullptr;
     int B = 0, max_frames = 0;
+    // streaming kernels: frames per run (0: chosen from B and max_frames) and the flat workgroup table of the batch
+    // (entry = clip << 12 | workgroup within the clip; null: a (workgroups of the longest clip) x B grid)
+    int run_frames = 0, n_wg = 0;
+    const int* wg_tab = nullptr;
     const float* sig = nullptr;
     const int* sig_off = nullptr;
     const int* sig_len = nullptr;
@@ -49,6 +55,8 @@ struct SynthLaunch {
     PlanDev plan;
     const int* frame_off = nullptr;
     int B = 0, max_frames = 0;
+    int n_wg = 0;
+    const int* wg_tab = nullptr;        // as in AnalysisLaunch, for runs of run_blocks hop blocks
     const float* amp = nullptr;
     const void* ph = nullptr;
     const void* full = nullptr;
