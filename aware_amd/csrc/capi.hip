@@ -530,13 +530,14 @@ extern "C" void aware_detector_destroy(aware_detector* d) {
 // (32-row blocks play the role of clips; plain epilogue), else on the f32-MFMA kernel.
 static void gemm_plain(int pipe, const float* A, int lda, const float* Bt, int ldb, const void* Bpk, const float* bias, float* C,
                        int ldc, int M, int N, int K, hipStream_t st) {
-    if (pipe == 0 && Bpk && M % 32 == 0 && gemm_clip_x3_supported(1, N, K, lda)) {
+    if (pipe == 0 && Bpk && gemm_clip_x3_supported(1, N, K, lda)) {
         // tile height: a workgroup streams its whole weight slab (6 K N/tn bytes) for its rows, so taller tiles cut the L2
-        // traffic of these short-K GEMMs; keep at least two workgroups per CU's worth of tiles
-        int g = 1;
-        const long blocks = (long)(M / 32) * (N / 128);
-        if ((M / 32) % 2 == 0 && blocks / 2 >= 512) g = 2;
-        launch_gemm_clip_x3(A, lda, Bpk, bias, C, ldc, M / (32 * g), g, 32 * g, N, K, 0, nullptr, nullptr, st);
+        // traffic of these short-K GEMMs; keep at least two workgroups per CU's worth of tiles.  M need not be a multiple
+        // of the tile height (ragged batches): the last row block is partial
+        const long blocks32 = (M + 31) / 32;
+        const int g = (blocks32 * (N / 128) / 2 >= 512) ? 2 : 1;
+        const int nb = (int)((M + 32 * g - 1) / (32 * g));
+        launch_gemm_clip_x3(A, lda, Bpk, bias, C, ldc, nb, g, 32 * g, N, K, 0, nullptr, nullptr, st, nullptr, nullptr, 0, M);
     } else
         launch_gemm_nt(A, lda, Bt, ldb, bias, C, ldc, M, N, K, st);
 }

@@ -243,7 +243,8 @@ __global__ __launch_bounds__(64 * NW, (RG <= 3 && NW == 8) ? 4 : 2) void gemm_cl
                                                                  int tiles_n, int ntiles, float* __restrict__ rstd_io,
                                                                  const float* __restrict__ act,
                                                                  const u32x4* __restrict__ Lpk, float* __restrict__ zpart,
-                                                                 int CL) {
+                                                                 int CL, int Mrows) {
+    // Mrows (X3_PLAIN only): rows of A and C that exist; the last row block may be partial (reads clamped, stores masked)
     constexpr int NTW = 8 / NW;           // 16-column tiles per wave (slab = 128 columns)
     constexpr int MT = 2 * RG;            // 16-row tiles per clip
     constexpr int MH = RG;
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(64 * NW, (RG <= 3 && NW == 8) ? 4 : 2) void gemm_cl
     const int r16 = lane & 15, kg = lane >> 4;
 
     f32x4 acc[MT][NTW];
-    x3_tile_gemm<RG, NW>(A, lda, Bpk, K, bm, bn, lds, acc, 32 * RG);
+    x3_tile_gemm<RG, NW>(A, lda, Bpk, K, bm, bn, lds, acc, EPI == X3_PLAIN ? min(32 * RG, Mrows - bm) : 32 * RG);
 
     // ---- epilogue: lane holds rows m*16 + 4*kg + e (e = 0..3) of columns cb + n*16 + r16 ----
     const int cb = bn + wave * (16 * NTW) + r16;
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(64 * NW, (RG <= 3 && NW == 8) ? 4 : 2) void gemm_cl
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int row = m * 16 + 4 * kg + e;
-                    C[(size_t)(bm + row) * ldc + col] = row < Tp ? acc[m][n][e] + bv : 0.f;
+                    if (bm + row < Mrows) C[(size_t)(bm + row) * ldc + col] = row < Tp ? acc[m][n][e] + bv : 0.f;
                 }
         } else if (EPI == X3_FWD || EPI == X3_FWD_LAST) {
             const float bv = bias ? bias[col] : 0.f;
@@ -825,9 +826,10 @@ constexpr int kSmallGrid = 128;
 
 void launch_gemm_clip_x3(const float* A, int lda, const void* Bpk, const float* bias, float* C, int ldc, int B, int nwm,
                          int Tp, int N, int K, int epi, float* rstd_io, const float* act, hipStream_t st,
-                         const void* lastpk, float* zpart, int CL) {
+                         const void* lastpk, float* zpart, int CL, int Mrows) {
     const int tn = N / 128;
-    if (tn * B < kSmallGrid && !(epi == X3_FWD && lastpk && zpart) && K % 32 == 0) {
+    if (Mrows <= 0) Mrows = B * 32 * nwm;
+    if (tn * B < kSmallGrid && Mrows == B * 32 * nwm && !(epi == X3_FWD && lastpk && zpart) && K % 32 == 0) {
         const int t16 = N / 16;
 #define SK(M_, E_) hipLaunchKernelGGL((gemm_clip_x3_small_kernel<M_, E_>), dim3(t16 * B), dim3(512), 0, st, A, lda,          \
                                       (const u32x4*)Bpk, bias, C, ldc, Tp, N, K, t16, rstd_io, act)
@@ -840,7 +842,7 @@ void launch_gemm_clip_x3(const float* A, int lda, const void* Bpk, const float* 
     if (epi == X3_FWD && lastpk && zpart) epi = X3_FWD_LAST;
 #define XK(M_, E_) hipLaunchKernelGGL((gemm_clip_x3_kernel<M_, E_, 8>), dim3(tn * B), dim3(512), 0, st, A, lda,          \
                                       (const u32x4*)Bpk, bias, C, ldc, Tp, N, K, tn, tn * B, rstd_io, act,                \
-                                      (const u32x4*)lastpk, zpart, CL)
+                                      (const u32x4*)lastpk, zpart, CL, Mrows)
 #define XM(E_) switch (nwm) { case 1: XK(1, E_); break; case 2: XK(2, E_); break; case 3: XK(3, E_); break; default: XK(4, E_); break; }
     if (epi == X3_FWD) { XM(X3_FWD) } else if (epi == X3_BWD) { XM(X3_BWD) } else if (epi == X3_FWD_LAST) { XM(X3_FWD_LAST) }
     else { XM(X3_PLAIN) }

@@ -114,7 +114,8 @@ bool gemm_clip_x3_supported(int nwm, int N, int K, int lda);
 // block (x3_pack of its weights zero-padded to a multiple of 16 rows), consumed by launch_readout_x3
 void launch_gemm_clip_x3(const float* A, int lda, const void* Bpk, const float* bias, float* C, int ldc, int B, int nwm,
                          int Tp, int N, int K, int epi, float* rstd_io, const float* act, hipStream_t st,
-                         const void* lastpk = nullptr, float* zpart = nullptr, int CL = 0);
+                         const void* lastpk = nullptr, float* zpart = nullptr, int CL = 0, int Mrows = 0);
+// (Mrows > 0, plain epilogue only: the matrices have Mrows < B*32*nwm rows -- the last row block is partial)
 // the same block for ragged batches / clips of any length (one launch; clips longer than 96 pooled frames in two passes)
 void launch_gemm_ragged_x3(const float* A, int lda, const void* Bpk, const float* bias, float* C, int ldc, int B,
                            const int* frame_off, const int* pool_off, int N, int K, int epi, float* rstd_io, const float* act,
