@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/aware_hip.h"
@@ -72,6 +73,8 @@ struct aware_batch {
     int an_run = 0, n_an_wg = 0, n_syn_wg = 0;
     int *d_an_wg = nullptr, *d_syn_wg = nullptr;
     std::vector<int> an_wg, syn_wg;
+    int* d_order = nullptr;            // clips longest first (dispatch order of the ragged GEMM: short clips fill the tail)
+    std::vector<int> order;
 };
 
 struct aware_detector {
@@ -244,7 +247,10 @@ extern "C" int aware_batch_create(aware_batch** out, int B, const int* n_samples
         b->n_an_wg = (int)b->an_wg.size();
         b->n_syn_wg = (int)b->syn_wg.size();
     }
-    const size_t ints = (size_t)(B + 1) * 2 + (size_t)B * 6 + b->an_wg.size() + b->syn_wg.size();
+    b->order.resize(B);
+    for (int i = 0; i < B; ++i) b->order[i] = i;
+    std::stable_sort(b->order.begin(), b->order.end(), [&](int x, int y) { return b->T[x] > b->T[y]; });
+    const size_t ints = (size_t)(B + 1) * 2 + (size_t)B * 7 + b->an_wg.size() + b->syn_wg.size();
     HIPCHK(hipMalloc((void**)&b->d_mem, ints * sizeof(int)));
     int* d = b->d_mem;
     auto up = [&](int*& dst, const std::vector<int>& v) -> hipError_t {
@@ -260,6 +266,7 @@ extern "C" int aware_batch_create(aware_batch** out, int B, const int* n_samples
     HIPCHK(up(b->d_out_len, b->out_len));
     HIPCHK(up(b->d_pc_in, b->pc_in));
     HIPCHK(up(b->d_pc_syn, b->pc_syn));
+    HIPCHK(up(b->d_order, b->order));
     if (b->n_an_wg) HIPCHK(up(b->d_an_wg, b->an_wg));
     if (b->n_syn_wg) HIPCHK(up(b->d_syn_wg, b->syn_wg));
     *out = b;
@@ -624,7 +631,7 @@ static int det_forward(const aware_detector* d, const aware_batch* b, const floa
         } else if (!nwm && pipe == 0 && co >= 128 && d->wpk[l] && gemm_clip_x3_supported(1, co, ci, ci)) {
             // ragged batch / clips longer than the uniform kernel's tile: conv + InstanceNorm + LeakyReLU in one launch,
             // clips walked in chunks of rows (gemm_ragged_x3_kernel)
-            launch_gemm_ragged_x3(x, ci, d->wpk[l], d->bias[l], o.act[l], co, b->B, b->d_frame_off, b->d_pool_off, co, ci, 1,
+            launch_gemm_ragged_x3(x, ci, d->wpk[l], d->bias[l], o.act[l], co, b->B, b->d_frame_off, b->d_pool_off, b->d_order, co, ci, 1,
                                   o.rstd[l], nullptr, st);
             LAUNCHCHK(); PROF(K_GEMM_X3_FWD);
         } else {
@@ -771,7 +778,7 @@ static int det_forward_backward(const aware_detector* d, const aware_batch* b, c
         } else if (!nwm && pipe == 0 && l > 0 && ci >= 128 && d->wTpk[l] && gemm_clip_x3_supported(1, ci, co, co)) {
             // ragged batch: data-gradient GEMM + backward of block l-1's InstanceNorm + LeakyReLU in one launch
             dz_ready = true;
-            launch_gemm_ragged_x3(dA, co, d->wTpk[l], nullptr, dB, ci, b->B, b->d_frame_off, b->d_pool_off, ci, co, 2,
+            launch_gemm_ragged_x3(dA, co, d->wTpk[l], nullptr, dB, ci, b->B, b->d_frame_off, b->d_pool_off, b->d_order, ci, co, 2,
                                   db.rstd[l - 1], db.act[l - 1], st);
             LAUNCHCHK(); PROF(K_GEMM_X3_BWD);
         } else {

@@ -574,8 +574,8 @@ template <int EPI>
 __global__ __launch_bounds__(512, 4) void gemm_ragged_x3_kernel(const float* __restrict__ A, int lda, const u32x4* __restrict__ Bpk,
                                                                 const float* __restrict__ bias, float* __restrict__ C, int ldc,
                                                                 const int* __restrict__ frame_off, const int* __restrict__ pool_off,
-                                                                int N, int K, int tiles_n, int ntiles, float* __restrict__ rstd_io,
-                                                                const float* __restrict__ act) {
+                                                                const int* __restrict__ order, int N, int K, int tiles_n, int ntiles,
+                                                                float* __restrict__ rstd_io, const float* __restrict__ act) {
     // blocks b and b + 8 share an XCD (observed round-robin placement; speed only): the slabs of one clip stay on one XCD
     // (its rows are read once into that L2), and clips are dealt to the XCDs round-robin -- batches arrive sorted by
     // length, a contiguous range per XCD would give one XCD all the long clips
@@ -590,6 +590,7 @@ __global__ __launch_bounds__(512, 4) void gemm_ragged_x3_kernel(const float* __r
             clip = id / tiles_n;
             slab = id % tiles_n;
         }
+        if (order) clip = order[clip];                              // dispatch position -> clip: longest clips first
     }
     const int bn = slab * 128;
     const int Tp = (frame_off[clip + 1] - frame_off[clip]) / 2;
@@ -663,16 +664,16 @@ __global__ __launch_bounds__(512, 4) void gemm_ragged_x3_kernel(const float* __r
 // epi: 1 forward (conv + InstanceNorm + LeakyReLU), 2 backward (data gradient + InstanceNorm/LeakyReLU backward of the
 // previous block); frame_off / pool_off: the batch's device tables
 void launch_gemm_ragged_x3(const float* A, int lda, const void* Bpk, const float* bias, float* C, int ldc, int B,
-                           const int* frame_off, const int* pool_off, int N, int K, int epi, float* rstd_io, const float* act,
-                           hipStream_t st) {
+                           const int* frame_off, const int* pool_off, const int* order, int N, int K, int epi, float* rstd_io,
+                           const float* act, hipStream_t st) {
     const int tn = N / 128;
     constexpr size_t kLds = 2 * 2 * 3 * (2 * kRaggedRG) * 1024;      // two K tiles of the tallest chunk
     if (epi == X3_FWD)
         hipLaunchKernelGGL((gemm_ragged_x3_kernel<X3_FWD>), dim3(tn * B), dim3(512), kLds, st, A, lda, (const u32x4*)Bpk, bias, C, ldc,
-                           frame_off, pool_off, N, K, tn, tn * B, rstd_io, act);
+                           frame_off, pool_off, order, N, K, tn, tn * B, rstd_io, act);
     else
         hipLaunchKernelGGL((gemm_ragged_x3_kernel<X3_BWD>), dim3(tn * B), dim3(512), kLds, st, A, lda, (const u32x4*)Bpk, bias, C, ldc,
-                           frame_off, pool_off, N, K, tn, tn * B, rstd_io, act);
+                           frame_off, pool_off, order, N, K, tn, tn * B, rstd_io, act);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -118,8 +118,9 @@ void launch_gemm_clip_x3(const float* A, int lda, const void* Bpk, const float* 
 // (Mrows > 0, plain epilogue only: the matrices have Mrows < B*32*nwm rows -- the last row block is partial)
 // the same block for ragged batches / clips of any length (one launch; clips longer than 96 pooled frames in two passes)
 void launch_gemm_ragged_x3(const float* A, int lda, const void* Bpk, const float* bias, float* C, int ldc, int B,
-                           const int* frame_off, const int* pool_off, int N, int K, int epi, float* rstd_io, const float* act,
-                           hipStream_t st);
+                           const int* frame_off, const int* pool_off, const int* order, int N, int K, int epi, float* rstd_io,
+                           const float* act, hipStream_t st);
+// (order: [B] clip indices, longest first, or null = as given; speed only)
 // fused read-out of the embed loop: last conv block + BRH + loss + their backward + data gradient of the last conv
 // + backward of the previous block's norm/activation (uniform batches; see gemm_x3.hip)
 bool readout_x3_supported(int nwm, int ci, int C);
