@@ -730,6 +730,7 @@ static int det_forward_backward(const aware_detector* d, const aware_batch* b, c
     float* dB = G.d2;
     bool dz_ready = false;      // dA already holds dL/dZ of layer l (fused into the producing kernel)
     int l_top = nl - 1;         // first layer the backward loop below still has to differentiate
+    bool last_k64 = false;      // dL/dZ of the last block was written with a row pitch of 64
     if (fused_readout) {
         launch_readout_x3(db.act[nl - 2], d->ch[nl - 1], db.zpart, d->ch[nl - 1] / 128, d->bias[nl - 1], d->lastTpk,
                           db.rstd[nl - 2], G.target, db.pred, G.loss, G.best_loss, G.improved, G.step, dA, b->B,
@@ -737,9 +738,13 @@ static int det_forward_backward(const aware_detector* d, const aware_batch* b, c
         dz_ready = true;
         l_top = nl - 2;
     } else if (db.tail) {
+        // ragged batch on the bf16x3 pipe: dL/dZ of the last block with a pitch of 64 (zero K padding), so that its data
+        // gradient runs on the ragged conv kernel with the previous block's InstanceNorm + LeakyReLU backward fused
+        last_k64 = !nwm && pipe == 0 && !G.wgrad && nl >= 2 && d->lastTpk && d->ch[nl] <= 64 &&
+                   gemm_clip_x3_supported(1, d->ch[nl - 1], 64, 64);
         launch_tail(db.zpart, kTailSplit, (size_t)b->NP * d->ch[nl], d->bias[nl - 1], b->d_frame_off, b->d_pool_off,
                     G.target, db.pred, G.loss, G.best_loss, G.improved, dA, G.step, G.loss_kind, d->nbits, b->B,
-                    b->max_frames / 2, st, G.loss_add);
+                    b->max_frames / 2, st, G.loss_add, last_k64 ? 64 : 0);
         dz_ready = true;
     } else {
         launch_head(db.act[nl - 1], b->d_frame_off, b->d_pool_off, G.target, db.pred, G.loss, G.best_loss,
@@ -775,6 +780,11 @@ static int det_forward_backward(const aware_detector* d, const aware_batch* b, c
                                  db.act[l - 1], st);
                 LAUNCHCHK(); PROF(K_GEMM_CLIP_BWD);
             }
+        } else if (l == nl - 1 && last_k64) {
+            dz_ready = true;
+            launch_gemm_ragged_x3(dA, 64, d->lastTpk, nullptr, dB, ci, b->B, b->d_frame_off, b->d_pool_off, b->d_order, ci, 64, 2,
+                                  db.rstd[l - 1], db.act[l - 1], st);
+            LAUNCHCHK(); PROF(K_GEMM_X3_BWD);
         } else if (!nwm && pipe == 0 && l > 0 && ci >= 128 && d->wTpk[l] && gemm_clip_x3_supported(1, ci, co, co)) {
             // ragged batch: data-gradient GEMM + backward of block l-1's InstanceNorm + LeakyReLU in one launch
             dz_ready = true;

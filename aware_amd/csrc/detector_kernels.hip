@@ -984,7 +984,8 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ zpa
                                                     float* __restrict__ pred, float* __restrict__ loss_out,
                                                     float* __restrict__ best_loss, int* __restrict__ improved,
                                                     float* __restrict__ dZ, int* __restrict__ step, int loss_kind, int nbits,
-                                                    const float* __restrict__ loss_add) {
+                                                    const float* __restrict__ loss_add, int ldz) {
+    // ldz: row pitch of dZ, C or 64 (columns C..63 are then written as zeros: K padding of the data-gradient GEMM)
     __shared__ float red[4][64], red2[4][64], mean_s[64], dm[64];
     const int b = blockIdx.x, c = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int r0 = pool_off[b], Tp = (frame_off[b + 1] - frame_off[b]) / 2;
@@ -1077,18 +1078,19 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ zpa
 #pragma unroll
     for (int i = 0; i < R; ++i) {
         const int t = g + 4 * i;
-        if (ok && t < Tpad) {
+        if (c < ldz && t < Tpad) {
             const float du = ga * (z[i] > 0.f ? 1.f : 0.2f);
-            dZ[(size_t)(r0 + t) * C + c] = (t < Tp) ? rs * (du - m1 - z[i] * m2) : 0.f;
+            dZ[(size_t)(r0 + t) * ldz + c] = (ok && t < Tp) ? rs * (du - m1 - z[i] * m2) : 0.f;
         }
     }
 }
 
 void launch_tail(const float* zpart, int nsplit, size_t slab, const float* bias, const int* frame_off, const int* pool_off,
                  const float* target, float* pred, float* loss, float* best_loss, int* improved, float* dZ, int* step,
-                 int loss_kind, int nbits, int B, int max_pooled, hipStream_t st, const float* loss_add) {
+                 int loss_kind, int nbits, int B, int max_pooled, hipStream_t st, const float* loss_add, int ldz) {
+    if (ldz < 2 * nbits) ldz = 2 * nbits;
 #define TL(S_, R_) hipLaunchKernelGGL((tail_kernel<S_, R_>), dim3(B), dim3(256), 0, st, zpart, slab, bias, frame_off, pool_off, \
-                                      target, pred, loss, best_loss, improved, dZ, step, loss_kind, nbits, loss_add)
+                                      target, pred, loss, best_loss, improved, dZ, step, loss_kind, nbits, loss_add, ldz)
     if (max_pooled <= 128) { if (nsplit == 4) TL(4, 32); else TL(1, 32); }
     else { if (nsplit == 4) TL(4, 80); else TL(1, 80); }
 #undef TL

@@ -147,7 +147,8 @@ void launch_gemm_nt_splitk(const float* A, int lda, const float* Bt, int ldb, fl
                            int ksplit, hipStream_t st);
 void launch_tail(const float* zpart, int nsplit, size_t slab, const float* bias, const int* frame_off, const int* pool_off,
                  const float* target, float* pred, float* loss, float* best_loss, int* improved, float* dZ, int* step,
-                 int loss_kind, int nbits, int B, int max_pooled, hipStream_t st, const float* loss_add = nullptr);
+                 int loss_kind, int nbits, int B, int max_pooled, hipStream_t st, const float* loss_add = nullptr, int ldz = 0);
+// (ldz: row pitch of dZ; 0 = 2*nbits, 64 = zero-padded to the K of the bf16x3 data-gradient GEMM)
 
 // ---- seam_kernels.hip: element-wise pieces of the differentiable plug-in seam -----------------------------
 void launch_polar_decompose(const void* spec, float* mag, float* phase, size_t n, hipStream_t st);
