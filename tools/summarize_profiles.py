@@ -48,6 +48,11 @@ with open(os.path.join(prof, f"{tag}_hbm_traffic_pmc.csv"), "w") as f:
         f.write(f'{B},"{name[:100]}",{int(grid)},{round(2 * v[len(v) // 2] / 1024, 1)},{round(w[len(w) // 2] / 1024, 1)},{mb}\n')
 src = glob.glob(os.path.join(raw, "kt_c3", "*", "*kernel_stats.csv"))[0]
 shutil.copy(src, os.path.join(prof, f"{tag}_bench_config3_kernel_stats.csv"))
-for n in ("bench_config3.json", "bench_config3_under_rocprof.json"):
-    shutil.copy(os.path.join(raw, n), os.path.join(prof, f"{tag}_{n}"))
+for n in ("bench_config3.json", "bench_config3_under_rocprof.json", "bench_config5.json", "bench_config2.json",
+          "gemm_power_probe.txt"):
+    if os.path.exists(os.path.join(raw, n)):
+        shutil.copy(os.path.join(raw, n), os.path.join(prof, f"{tag}_{n}"))
+c5 = glob.glob(os.path.join(raw, "kt_c5", "*", "*kernel_stats.csv"))
+if c5:
+    shutil.copy(c5[0], os.path.join(prof, f"{tag}_bench_config5_kernel_stats.csv"))
 print("profiles written for", tag)
