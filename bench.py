@@ -145,6 +145,37 @@ def cpu_baseline(workload):
                       f"({t_det*1e3:.1f} ms); vectorised bounds (no 1.3 s/clip Python loop)"}
 
 
+def gemm_clock_envelope(rt, clips, tp):
+    """The dominant kernel on one shape (1024 -> 1024 conv block of this batch, plain epilogue), timed on random operands
+    and on all-zero operands: cycles per MFMA do not depend on the data, the clock the chip holds under MFMA load does
+    (MI355X_MICROARCH.md, DVFS give-back), so the ratio separates issue efficiency from the power envelope."""
+    import torch
+    rows = clips * 32 * ((tp + 31) // 32)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    out = {}
+    for kind in ("random", "zeros"):
+        if kind == "zeros":
+            a, w = torch.zeros((rows, 1024), device="cuda"), torch.zeros((1024, 1024), device="cuda")
+        else:
+            a = torch.randn((rows, 1024), device="cuda", generator=g)
+            w = torch.randn((1024, 1024), device="cuda", generator=g) / 32
+        packed = rt.x3_pack(w)
+        for _ in range(3):
+            rt.gemm_clip(a, w, None, clips, tp, 0, mode=1, packed=packed)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            rt.gemm_clip(a, w, None, clips, tp, 0, mode=1, packed=packed)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        out[kind + "_TFLOPs"] = round(2.0 * rows * 1024 * 1024 / (ms * 1e-3) / 1e12, 1)
+    out["frac_of_peak_on_zeros"] = round(out["zeros_TFLOPs"] / (MFMA_BF16_PEAK_TF / 6.0), 3)
+    out["note"] = ("same binary, same shape, f32-equivalent TFLOP/s on random and on all-zero operands: the gap is the clock the "
+                   "chip holds on random bf16 data, not issue slots (DESIGN.md section 4, profiles/r02_gemm_power_probe.txt)")
+    return out
+
+
 def pmc_traffic_per_launch(per_gpu):
     """Mean HBM bytes per launch of the dominant kernel from the PMC passes stored under profiles/ (same command, same
     batch; separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs -- bench.py cannot collect counters itself).
@@ -340,6 +371,7 @@ def main():
             pairs = [(ch[0], ch[1]), (ch[1], ch[2]), (ch[2], ch[3]), (ch[3], ch[2]), (ch[2], ch[1])]
             alg = sum(4.0 * rows * (k + n) + 6.0 * k * n for k, n in pairs) + 4.0 * rows * (ch[2] + ch[1])
             roof["algorithmic_bytes_per_launch"] = round(alg / 5)
+            roof["clock_envelope"] = gemm_clock_envelope(rt, len(batch.frames), batch.frames[0] // 2)
     if world > 1:
         import torch.distributed as dist
         parallel.barrier()
