@@ -75,26 +75,66 @@ __global__ __launch_bounds__(256) void upfirdn_kernel(const float* __restrict__ 
 // Direct-form-II-transposed IIR in float64 (scipy lfilter / filtfilt), one workgroup per clip, parallel in time.
 // The recurrence is linear, so a clip is cut into kIirChunks chunks of L samples, one per thread:
 //   pass A  every thread runs the recurrence over its chunk from a ZERO state (thread 0: from the true initial state)
-//           and keeps only the end state v[c]; meanwhile a fifth wave runs the zero-input recurrence from the unit
-//           states for L steps, which gives the L-step state transition matrix M;
+//           and keeps only the end state v[c]; meanwhile one more wave computes the L-step state transition matrix
+//           M = A^L (A = one zero-input step): A^16 by running 16 steps from the unit states, then square-and-multiply;
 //   pass B  one wave chains the true chunk-start states z0[c+1] = M z0[c] + v[c] (lane k owns row k of M);
 //   pass C  every thread runs the same recurrence again over its chunk from its true start state and stores y.
-// The samples a thread emits are those of the sequential algorithm started from a state that differs from the
-// sequential one by the rounding of pass B (relative 1e-16): far below the float32 result of the attacks.
+// Passes A and C are the sequential algorithm in plain float64.  M and pass B are in DOUBLE-DOUBLE: the transposed direct
+// form of a narrow band-stop (eight poles in two tight clusters near the unit circle) is far from normal -- |M| reaches
+// 1e7..1e8 while M z0 stays O(|z0|) -- so a float64 M z0 loses 7-8 digits to cancellation (measured: 3e-2 absolute error
+// on a 400 Hz band, against 1.5e-8 for the sequential recurrence itself).  With M and the chaining exact to 1e-32 the
+// result differs from scipy's by no more than the sequential recurrence's own rounding (5e-8 at a 300 Hz band, 1e-11 at
+// 2.5 kHz; tests/test_gpu_attacks.py::test_iir_time_parallel_long_ragged).
 //   mode 0: lfilter with zero state (LowPassFilter / HighPassFilter, attacks.py:400-455).
 //   mode 1: filtfilt (RandomBandstop, attacks.py:324-356): odd extension by 3*ncoef samples, steady-state initial
 //           conditions zi*x0, forward then backward; needs scratch[B][maxlen + 6*ncoef] doubles.
 constexpr int kMaxCoef = 12;
-constexpr int kIirChunks = 256;                  // worker threads (= chunks) per clip; + one wave for the matrix
+constexpr int kIirChunks = 128;                  // worker threads (= chunks) per clip; + one wave for the matrix
+
+struct dd { double hi, lo; };                    // unevaluated sum hi + lo, |lo| <= ulp(hi)/2
+// The error-free transformations below are exact only as written: no contraction of a product into a neighbouring add
+// (hipcc's default -ffp-contract=fast fused `p + e` with the multiplication that produced p and destroyed the low words).
+__device__ __forceinline__ dd dd_renorm(double s, double e) {
+#pragma clang fp contract(off)
+    const double h = s + e;
+    return dd{h, e - (h - s)};
+}
+__device__ __forceinline__ dd dd_add(dd a, dd b) {
+#pragma clang fp contract(off)
+    const double s = a.hi + b.hi, bb = s - a.hi;
+    const double e = ((a.hi - (s - bb)) + (b.hi - bb)) + (a.lo + b.lo);
+    return dd_renorm(s, e);
+}
+__device__ __forceinline__ dd dd_mul(dd a, dd b) {
+#pragma clang fp contract(off)
+    const double p = a.hi * b.hi;
+    const double c1 = a.hi * b.lo, c2 = a.lo * b.hi;
+    const double e = __builtin_fma(a.hi, b.hi, -p) + (c1 + c2);
+    return dd_renorm(p, e);
+}
+__device__ __forceinline__ dd dd_mul_d(dd a, double b) {
+#pragma clang fp contract(off)
+    const double p = a.hi * b;
+    const double c1 = a.lo * b;
+    const double e = __builtin_fma(a.hi, b, -p) + c1;
+    return dd_renorm(p, e);
+}
+__device__ __forceinline__ dd dd_neg(dd a) { return dd{-a.hi, -a.lo}; }
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)b, lane), hi = __builtin_amdgcn_readlane((unsigned)(b >> 32), lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 template <int NC>
 __global__ __launch_bounds__(kIirChunks + 64) void iir_kernel(const float* __restrict__ in, const int* __restrict__ off,
                                                               const int* __restrict__ len, void* __restrict__ outv,
                                                               int out_f64, const double* __restrict__ bc,
                                                               const double* __restrict__ ac, const double* __restrict__ zic,
                                                               int mode, double* __restrict__ scratch, int sstride) {
-    constexpr int NS = NC - 1, NT = kIirChunks, CH = 16;
+    constexpr int NS = NC - 1, NT = kIirChunks, CH = 16, NE = NS * NS;
     __shared__ double Vs[NT][NS];                // pass A: zero-state end states; after pass B: true start states
-    __shared__ double Ms[NS][NS];
+    __shared__ dd Mx[3][NE];                     // matrix wave: result / running power / product; Mx[0] = M at the end
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const bool matrix_wave = tid >= NT;
     double bb[NC], aa[NC], z[NS];
@@ -118,22 +158,64 @@ __global__ __launch_bounds__(kIirChunks + 64) void iir_kernel(const float* __res
     double* s = scratch + (size_t)b * sstride;
 
     if (matrix_wave) {
-        // column j of M: the state after L zero-input steps from the unit state e_j
-        const int j = lane < NS ? lane : NS - 1;
+        // A^16, column j on lane j: 16 zero-input steps from the unit state e_j, in double-double
+        volatile dd* R = Mx[0];
+        volatile dd* P = Mx[1];
+        volatile dd* T = Mx[2];
+        {
+            const int j = lane < NS ? lane : NS - 1;
+            dd zz[NS];
 #pragma unroll
-        for (int k = 0; k < NS; ++k) z[k] = k == j ? 1.0 : 0.0;
-        for (int i = 0; i < L; ++i) step(0.0);
-        if (lane < NS) {
+            for (int k = 0; k < NS; ++k) zz[k] = dd{k == j ? 1.0 : 0.0, 0.0};
+            for (int i = 0; i < CH; ++i) {
+                const dd yi = zz[0];
 #pragma unroll
-            for (int k = 0; k < NS; ++k) Ms[k][j] = z[k];
+                for (int k = 0; k < NS - 1; ++k) zz[k] = dd_add(zz[k + 1], dd_neg(dd_mul_d(yi, aa[k + 1])));
+                zz[NS - 1] = dd_neg(dd_mul_d(yi, aa[NS]));
+            }
+            if (lane < NS) {
+#pragma unroll
+                for (int k = 0; k < NS; ++k) { P[k * NS + j].hi = zz[k].hi; P[k * NS + j].lo = zz[k].lo; }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // M = (A^16)^(L/16) by square-and-multiply (all factors are powers of A, so the order of a product is free);
+        // entry (i, l) of a product on lane i*NS + l (two rounds of lanes when NS*NS > 64)
+        auto matmul = [&](volatile dd* X, volatile dd* Y, volatile dd* Z) {     // Z = X Y
+            for (int e = lane; e < NE; e += 64) {
+                const int i = e / NS, l = e % NS;
+                dd acc{0.0, 0.0};
+                for (int q = 0; q < NS; ++q) {
+                    const dd xv{X[i * NS + q].hi, X[i * NS + q].lo}, yv{Y[q * NS + l].hi, Y[q * NS + l].lo};
+                    acc = dd_add(acc, dd_mul(xv, yv));
+                }
+                Z[e].hi = acc.hi; Z[e].lo = acc.lo;
+            }
+            __builtin_amdgcn_wave_barrier();
+        };
+        auto copy = [&](volatile dd* X, volatile dd* Z) {
+            for (int e = lane; e < NE; e += 64) { Z[e].hi = X[e].hi; Z[e].lo = X[e].lo; }
+            __builtin_amdgcn_wave_barrier();
+        };
+        int ex = L / CH;
+        bool have = false;
+        while (ex) {
+            if (ex & 1) {
+                if (!have) { copy(P, R); have = true; }
+                else { matmul(R, P, T); copy(T, R); }
+            }
+            ex >>= 1;
+            if (ex) { matmul(P, P, T); copy(T, P); }
         }
     }
     if (mode && !matrix_wave) {
         // odd extension (scipy filtfilt padtype='odd', padlen = 3*max(len(a), len(b)))
         const double x0 = (double)x[0], xl = (double)x[n - 1];
         for (int i = tid; i < edge; i += NT) {
-            s[i] = 2.0 * x0 - (double)x[edge - i];
-            s[edge + n + i] = 2.0 * xl - (double)x[n - 2 - i];
+            // (a clip no longer than the padding is refused by the host binding, as scipy refuses it; the clamps keep
+            //  a direct C-ABI call with such a clip inside its buffer)
+            s[i] = 2.0 * x0 - (double)x[min(edge - i, n - 1)];
+            s[edge + n + i] = 2.0 * xl - (double)x[max(n - 2 - i, 0)];
         }
         for (int i = tid; i < n; i += NT) s[edge + i] = (double)x[i];
     }
@@ -161,18 +243,17 @@ __global__ __launch_bounds__(kIirChunks + 64) void iir_kernel(const float* __res
         __syncthreads();
         if (tid < 64) {
             const int k = lane < NS ? lane : NS - 1;
-            double mrow[NS];
+            dd mrow[NS];
 #pragma unroll
-            for (int q = 0; q < NS; ++q) mrow[q] = Ms[k][q];
-            double cur = Vs[0][k];                               // thread 0 started from the true state
+            for (int q = 0; q < NS; ++q) mrow[q] = Mx[0][k * NS + q];
+            dd cur{Vs[0][k], 0.0};                               // thread 0 started from the true state
             for (int c = 1; c < nch; ++c) {
-                double nxt = Vs[c][k];
-                if (lane < NS) Vs[c][k] = cur;
-                const unsigned lo = (unsigned)__double_as_longlong(cur), hi = (unsigned)(__double_as_longlong(cur) >> 32);
+                dd nxt{Vs[c][k], 0.0};
+                if (lane < NS) Vs[c][k] = cur.hi;                // true start state of chunk c, rounded to float64
 #pragma unroll
                 for (int q = 0; q < NS; ++q) {
-                    const unsigned ql = __builtin_amdgcn_readlane(lo, q), qh = __builtin_amdgcn_readlane(hi, q);
-                    nxt += mrow[q] * __longlong_as_double((long long)(((unsigned long long)qh << 32) | ql));
+                    const dd cq{readlane_d(cur.hi, q), readlane_d(cur.lo, q)};
+                    nxt = dd_add(nxt, dd_mul(mrow[q], cq));
                 }
                 cur = nxt;
             }

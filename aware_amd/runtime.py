@@ -517,6 +517,8 @@ def iir(x: Ragged, b: np.ndarray, a: np.ndarray, zi: np.ndarray | None = None, f
     bd = torch.as_tensor(np.ascontiguousarray(b, dtype=np.float64), device=dev)
     ad = torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=dev)
     ncoef = bd.shape[1]
+    if filtfilt and min(x.lengths) <= 3 * ncoef:           # scipy.signal.filtfilt raises the same way (padlen = 3*max(len(a), len(b)))
+        raise ValueError(f"The length of the input vector x must be greater than padlen, which is {3 * ncoef}.")
     zd = None if zi is None else torch.as_tensor(np.ascontiguousarray(zi, dtype=np.float64), device=dev)
     out = x.like(torch.float64 if out_f64 else torch.float32)
     scr = torch.empty(x.B * (x.max_len + 6 * ncoef), dtype=torch.float64, device=dev) if filtfilt else None

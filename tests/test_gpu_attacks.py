@@ -241,3 +241,45 @@ def test_delete_015_and_3s_attack_fixture(A, gold, gold2):
         # BER after the attack equals the reference's (0 errors on this clip for every attack)
         np.testing.assert_array_equal((v > 0).astype(np.int32), (gold2[f"3s/{k}/det_raw"] > 0).astype(np.int32))
         assert int(((v > 0).astype(np.int32) != bits).sum()) == 0
+
+
+def test_iir_time_parallel_long_ragged(A):
+    """The chunked (time-parallel) IIR kernel against scipy's sequential lfilter / filtfilt in float64 on ragged clips of
+    up to 10 s: every chunk count from 1 to 256, a different filter per clip.  The kernel restarts the same recurrence
+    from propagated chunk-start states, so float64 results agree to rounding (1e-12 of the signal scale); the float32
+    outputs of the attacks agree to one float32 rounding."""
+    from scipy import signal
+    from aware_amd import runtime as rt
+    rng = np.random.default_rng(5)
+    lens = [16000, 160000, 9000, 123457, 40, 4097, 70001]
+    clips = [(0.1 * rng.standard_normal(n)).astype(np.float32) for n in lens]
+    x = rt.Ragged.from_list(clips)
+    # lfilter, float64 out: per-clip Butterworth low-pass / high-pass of order 6 (7 coefficients)
+    ba = [signal.butter(6, (2000 + 500 * i) / 8000, "low" if i % 2 == 0 else "highpass") for i in range(len(lens))]
+    b = np.stack([p[0] for p in ba]); a = np.stack([p[1] for p in ba])
+    y = rt.iir(x, b, a, out_f64=True).to_list()
+    for i, c in enumerate(clips):
+        ref = signal.lfilter(ba[i][0], ba[i][1], c.astype(np.float64))
+        assert np.max(np.abs(y[i] - ref)) < 1e-12 * max(1.0, np.max(np.abs(ref))), (i, np.max(np.abs(y[i] - ref)))
+    # the ill-conditioned end of RandomBandstop's range (f_low = 300 / 400 Hz: eight poles in two tight clusters, chunk
+    # transition matrices of norm 1e7-1e8): the double-double chaining keeps the result within the sequential recurrence's
+    # own rounding (scipy float64 vs the same recurrence in 80-bit arithmetic: 4e-8 / 1.6e-8)
+    for f_low in (300.0, 400.0):
+        bl, al = signal.butter(4, [f_low / 8000, (f_low + 200.0) / 8000], "bandstop")
+        yl = rt.iir(rt.Ragged.from_list(clips[:2]), np.stack([bl, bl]), np.stack([al, al]), out_f64=True).to_list()
+        for c, got in zip(clips[:2], yl):
+            ref = signal.lfilter(bl, al, c.astype(np.float64))
+            assert np.max(np.abs(got - ref)) < 3e-7, (f_low, np.max(np.abs(got - ref)))
+    # filtfilt (order-4 band-stop = 9 coefficients, a different band per clip), float32 out like RandomBandstop
+    lens2 = [16000, 160000, 9000, 123457, 4097]
+    clips2 = [(0.1 * rng.standard_normal(n)).astype(np.float32) for n in lens2]
+    x2 = rt.Ragged.from_list(clips2)
+    bs = [signal.butter(4, [(400 + 700 * i) / 8000, (600 + 700 * i) / 8000], "bandstop") for i in range(len(lens2))]
+    b2 = np.stack([p[0] for p in bs]); a2 = np.stack([p[1] for p in bs])
+    zi = np.stack([signal.lfilter_zi(p[0], p[1]) for p in bs])
+    y2 = rt.iir(x2, b2, a2, zi, filtfilt=True).to_list()
+    for i, c in enumerate(clips2):
+        ref = signal.filtfilt(bs[i][0], bs[i][1], c.astype(np.float64))
+        np.testing.assert_allclose(y2[i], ref.astype(np.float32), atol=1.2e-7 * max(1.0, float(np.max(np.abs(ref)))))
+    with pytest.raises(ValueError, match="greater than padlen"):
+        rt.iir(rt.Ragged.from_list([clips[0][:20]]), b2[:1], a2[:1], zi[:1], filtfilt=True)
