@@ -734,7 +734,9 @@ static int det_forward_backward(const aware_detector* d, const aware_batch* b, c
     if (fused_readout) {
         launch_readout_x3(db.act[nl - 2], d->ch[nl - 1], db.zpart, d->ch[nl - 1] / 128, d->bias[nl - 1], d->lastTpk,
                           db.rstd[nl - 2], G.target, db.pred, G.loss, G.best_loss, G.improved, G.step, dA, b->B,
-                          nwm, b->uniform_tp, d->ch[nl], d->nbits, G.loss_kind, st, G.loss_add);
+                          nwm, b->uniform_tp, d->ch[nl], d->nbits, G.loss_kind, st, G.loss_add, dB);
+        // (dB, the other half of the gradient ping-pong, is free until the next data-gradient GEMM writes it: it holds the
+        //  read-out's fragment image, readout_x3_image_bytes = 36 KB per 3 s clip, far below NP * maxc floats)
         dz_ready = true;
         l_top = nl - 2;
     } else if (db.tail) {

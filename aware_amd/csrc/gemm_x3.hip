@@ -863,20 +863,22 @@ bool gemm_clip_x3_supported(int nwm, int N, int K, int lda) {
 // GEMM, tail kernel, clip-aligned data-gradient GEMM) whose work is tiny and latency-bound.
 //   reference: detection/multibit_detector_net.py:58-70,133-140 (last block + BRH), modules/BRH.py:16-27,
 //              embedding/losses.py, embedding/multibit_embedder.py:109-122 (loss, best tracking)
-// Grid: G workgroups per clip (G = Cin/256); each recomputes the clip's [Tp x C] forward (K = Cin, 8 waves =
-// one 16-row tile per wave, A split in registers straight from global memory, no LDS), then owns 256 of the
-// Cin columns of the data gradient.  Only workgroup g = 0 of a clip writes pred / loss / best tracking.
+// Two launches (round 2; one kernel with G workgroups per clip redid the head G times -- 38 of its 82 us at B = 256):
+//   readout_head_x3_kernel  one workgroup per clip: sums the clip's split-K partials, InstanceNorm, LeakyReLU, BRH, loss,
+//                           bookkeeping and the backward of all of it; leaves dL/dZ of the last block as bf16x3 A fragments
+//                           (k = channel, zero-padded to 64) in a scratch image of IMG bytes per clip;
+//   readout_grad_x3_kernel  G = Cin/128 workgroups per clip, one 16-column tile per wave, no LDS, no barrier: the data
+//                           gradient of the last conv from the image (fragments straight from L2) with the backward of
+//                           the previous block's InstanceNorm + LeakyReLU in its epilogue.
 // ---------------------------------------------------------------------------------------------------
 template <int RG, int NC>
-__global__ __launch_bounds__(512) void readout_x3_kernel(const float* __restrict__ hin, int ci,
-                                                          const float* __restrict__ zpart, int nslab, size_t slab_stride,
-                                                          const float* __restrict__ bias,
-                                                          const u32x4* __restrict__ WTpk, const float* __restrict__ rstd_prev,
-                                                          const float* __restrict__ target, float* __restrict__ pred,
-                                                          float* __restrict__ loss_out, float* __restrict__ best_loss,
-                                                          int* __restrict__ improved, int* __restrict__ step,
-                                                          float* __restrict__ dZ, int Tp, int C, int nbits, int loss_kind,
-                                                          int G, int ntiles, const float* __restrict__ loss_add) {
+__global__ __launch_bounds__(512) void readout_head_x3_kernel(const float* __restrict__ zpart, int nslab, size_t slab_stride,
+                                                               const float* __restrict__ bias, const float* __restrict__ target,
+                                                               float* __restrict__ pred, float* __restrict__ loss_out,
+                                                               float* __restrict__ best_loss, int* __restrict__ improved,
+                                                               int* __restrict__ step, unsigned char* __restrict__ img_out,
+                                                               int Tp, int C, int nbits, int loss_kind,
+                                                               const float* __restrict__ loss_add) {
     constexpr int MT = 2 * RG;
     constexpr int FRAG = 1024;
     constexpr int KSC = 2;                           // K32 steps of the data-gradient GEMM (C <= 64)
@@ -885,9 +887,7 @@ __global__ __launch_bounds__(512) void readout_x3_kernel(const float* __restrict
     __shared__ float red[6][8][64];
     __shared__ float mean_s[64], dm[64];
 
-    int id = blockIdx.x;
-    if ((ntiles & 7) == 0) id = (id & 7) * (ntiles >> 3) + (id >> 3);
-    const int clip = id / G, g = id % G;
+    const int clip = blockIdx.x, g = 0;
     const int bm = clip * 32 * RG;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kg = lane >> 4;
@@ -1065,104 +1065,162 @@ __global__ __launch_bounds__(512) void readout_x3_kernel(const float* __restrict
             }
         }
     }
-    // operands of phase 3 that do not depend on this kernel's own work are requested before the barrier: the weight
-    // fragments and the previous block's activations (read again by the fused backward below)
-    const int ntb = g * 16 + 2 * wave;                  // first 16-column tile of this wave
-    u32x4 bw[KSC][2][3];
+    __syncthreads();
+    // the finished image goes to the clip's slot of the scratch buffer, 16 bytes per thread and round
+    uint4* dst = reinterpret_cast<uint4*>(img_out + (size_t)clip * IMG);
+    for (int i = tid; i < IMG / 16; i += 512) dst[i] = reinterpret_cast<const uint4*>(img)[i];
+}
+
+template <int RG>
+__global__ __launch_bounds__(512, RG <= 3 ? 4 : 2) void readout_grad_x3_kernel(const float* __restrict__ hin, int ci,
+                                                                                const unsigned char* __restrict__ img_in,
+                                                                                const u32x4* __restrict__ WTpk,
+                                                                                const float* __restrict__ rstd_prev,
+                                                                                float* __restrict__ dZ, int Tp, int G, int ntiles) {
+    constexpr int MT = 2 * RG;
+    constexpr int FRAG = 1024;
+    constexpr int KSC = 2;
+    constexpr int IMG = KSC * 3 * MT * FRAG;
+    int id = blockIdx.x;
+    if ((ntiles & 7) == 0) id = (id & 7) * (ntiles >> 3) + (id >> 3);
+    const int clip = id / G, g = id % G;
+    const int bm = clip * 32 * RG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kg = lane >> 4;
+    const float invT = 1.0f / (float)Tp;
+    const unsigned char* img = img_in + (size_t)clip * IMG;
+    const int ntb = g * 8 + wave;                       // the 16-column tile of this wave
+    u32x4 bw[KSC][3];
 #pragma unroll
     for (int t = 0; t < KSC; ++t)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int p = 0; p < 3; ++p) bw[t][p] = WTpk[(((size_t)ntb * KSC + t) * 3 + p) * 64 + lane];
+    // Global memory is touched in a ROW-MAJOR layout, not in the accumulator's: lane = 4 consecutive columns (16 bytes), half
+    // a wave = one 512-byte row segment, rows rr + 16 j.  In the accumulator layout a wave instruction covers 4 rows x 64 bytes
+    // and this kernel -- which only streams one activation in and one gradient out -- ran at 3.0 TB/s; the same bytes in
+    // this layout move at 6 TB/s (measured, timing-only ablation).  The MFMA result changes layout through LDS.
+    // (the fragment image and the transposed tile share LDS: every wave reads all of the clip's A fragments, 36 KB, and
+    //  re-reading them per wave from L2 through the texture path cost more than the streaming itself)
+    constexpr int TBYTES = 32 * RG * 132 * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_buf[TBYTES > IMG ? TBYTES : IMG];
+    __shared__ float red[2][8][128];
+    float (*T)[132] = reinterpret_cast<float (*)[132]>(lds_buf);
+    for (int i = tid; i < IMG / 16; i += 512) reinterpret_cast<uint4*>(lds_buf)[i] = reinterpret_cast<const uint4*>(img)[i];
+    const int c4 = (lane & 31) * 4, rr = 2 * wave + (lane >> 5);
+    const size_t gcol = (size_t)g * 128 + c4;
+    float4 hv[MT];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bw[t][n][p] = WTpk[(((size_t)(ntb + n) * KSC + t) * 3 + p) * 64 + lane];
-    float hv[2][MT][4];
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)     // unconditional (padding rows exist and hold zeros): see gemm_clip_x3_kernel
-                hv[n][m][e] = hin[(size_t)(bm + m * 16 + 4 * kg + e) * ci + (ntb + n) * 16 + r16];
+    for (int j2 = 0; j2 < MT; ++j2)         // unconditional (padding rows exist and hold zeros)
+        hv[j2] = *reinterpret_cast<const float4*>(hin + (size_t)(bm + rr + 16 * j2) * ci + gcol);
+    const float4 rsp = *reinterpret_cast<const float4*>(rstd_prev + (size_t)clip * ci + gcol);
     __syncthreads();
 
-    // ---- phase 3: dL/dh = dZ_last * W, 32 columns per wave, fused backward of the previous block ----
-    f32x4 acc[MT][2];
+    // ---- dL/dh = dZ_last * W, 16 columns per wave, fused backward of the previous block ----
+    f32x4 acc[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) { acc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < KSC; ++t) {
-        bf16x8 b[2][3], a[MT][3];
+        bf16x8 b[3];
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(bf16x8, bw[t][p]);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) b[n][p] = __builtin_bit_cast(bf16x8, bw[t][n][p]);
+        for (int hf = 0; hf < 2; ++hf) {                // row tiles by halves: RG fragments x 3 planes in registers at a time
+            bf16x8 a[RG][3];
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+            for (int m = 0; m < RG; ++m)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) a[m][p] = *reinterpret_cast<const bf16x8*>(img + (size_t)((t * 3 + p) * MT + m) * FRAG + lane * 16);
+                for (int p = 0; p < 3; ++p)
+                    a[m][p] = *reinterpret_cast<const bf16x8*>(lds_buf + (size_t)((t * 3 + p) * MT + hf * RG + m) * FRAG + lane * 16);
 #pragma unroll
-        for (int term = 0; term < 6; ++term) {
-            const int pa = term == 0 ? 2 : (term == 1 || term == 3) ? 1 : 0;
-            const int pb = term == 2 ? 2 : (term == 1 || term == 4) ? 1 : 0;
+            for (int term = 0; term < 6; ++term) {
+                const int pa = term == 0 ? 2 : (term == 1 || term == 3) ? 1 : 0;
+                const int pb = term == 2 ? 2 : (term == 1 || term == 4) ? 1 : 0;
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][pa], b[n][pb], acc[m][n], 0, 0, 0);
+                for (int m = 0; m < RG; ++m)
+                    acc[hf * RG + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][pa], b[pb], acc[hf * RG + m], 0, 0, 0);
+            }
         }
     }
+    __syncthreads();                                   // every wave has read its fragments: the buffer becomes the tile
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        const int col = (ntb + n) * 16 + r16;
-        const float rsp = rstd_prev[(size_t)clip * ci + col];
-        float s1 = 0.f, s2 = 0.f;
-        float u[MT][4];
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int e = 0; e < 4; ++e) T[16 * m + 4 * kg + e][16 * wave + r16] = acc[m][e];
+    __syncthreads();
+    float4 du[MT];
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int row = m * 16 + 4 * kg + e;
-                const float av = hv[n][m][e];
-                const bool valid = row < Tp;
-                const float uv = valid ? (av > 0.f ? av : av * 5.0f) : 0.f;                 // invert LeakyReLU(0.2)
-                const float du = valid ? acc[m][n][e] * (av > 0.f ? 1.f : 0.2f) : 0.f;
-                acc[m][n][e] = du;
-                u[m][e] = uv;
-                s1 += du;
-                s2 += du * uv;
-            }
-        s1 += __shfl_xor(s1, 16);
-        s1 += __shfl_xor(s1, 32);
-        s2 += __shfl_xor(s2, 16);
-        s2 += __shfl_xor(s2, 32);
-        const float m1 = s1 * invT, m2 = s2 * invT;
+    for (int j2 = 0; j2 < MT; ++j2) {
+        const int row = rr + 16 * j2;
+        const float4 gacc = *reinterpret_cast<const float4*>(&T[row][c4]);
+        const bool valid = row < Tp;
+        auto one = [&](float gv, float& av, float& d, float& a1, float& a2) {
+            const float uv = valid ? (av > 0.f ? av : av * 5.0f) : 0.f;                 // invert LeakyReLU(0.2)
+            d = valid ? gv * (av > 0.f ? 1.f : 0.2f) : 0.f;
+            av = uv;
+            a1 += d;
+            a2 += d * uv;
+        };
+        one(gacc.x, hv[j2].x, du[j2].x, s1.x, s2.x);
+        one(gacc.y, hv[j2].y, du[j2].y, s1.y, s2.y);
+        one(gacc.z, hv[j2].z, du[j2].z, s1.z, s2.z);
+        one(gacc.w, hv[j2].w, du[j2].w, s1.w, s2.w);
+    }
+    // column sums: the two row halves of the wave, then the eight waves
+    s1.x += __shfl_xor(s1.x, 32); s1.y += __shfl_xor(s1.y, 32); s1.z += __shfl_xor(s1.z, 32); s1.w += __shfl_xor(s1.w, 32);
+    s2.x += __shfl_xor(s2.x, 32); s2.y += __shfl_xor(s2.y, 32); s2.z += __shfl_xor(s2.z, 32); s2.w += __shfl_xor(s2.w, 32);
+    if (lane < 32) {
+        *reinterpret_cast<float4*>(&red[0][wave][c4]) = s1;
+        *reinterpret_cast<float4*>(&red[1][wave][c4]) = s2;
+    }
+    __syncthreads();
+    float4 m1 = make_float4(0.f, 0.f, 0.f, 0.f), m2 = m1;
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+    for (int w = 0; w < 8; ++w) {
+        const float4 p1 = *reinterpret_cast<const float4*>(&red[0][w][c4]), p2 = *reinterpret_cast<const float4*>(&red[1][w][c4]);
+        m1.x += p1.x; m1.y += p1.y; m1.z += p1.z; m1.w += p1.w;
+        m2.x += p2.x; m2.y += p2.y; m2.z += p2.z; m2.w += p2.w;
+    }
+    m1.x *= invT; m1.y *= invT; m1.z *= invT; m1.w *= invT;
+    m2.x *= invT; m2.y *= invT; m2.z *= invT; m2.w *= invT;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int row = m * 16 + 4 * kg + e;
-                dZ[(size_t)(bm + row) * ci + col] = row < Tp ? rsp * (acc[m][n][e] - m1 - u[m][e] * m2) : 0.f;
-            }
+    for (int j2 = 0; j2 < MT; ++j2) {
+        const int row = rr + 16 * j2;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < Tp) {
+            o.x = rsp.x * (du[j2].x - m1.x - hv[j2].x * m2.x);
+            o.y = rsp.y * (du[j2].y - m1.y - hv[j2].y * m2.y);
+            o.z = rsp.z * (du[j2].z - m1.z - hv[j2].z * m2.z);
+            o.w = rsp.w * (du[j2].w - m1.w - hv[j2].w * m2.w);
+        }
+        *reinterpret_cast<float4*>(dZ + (size_t)(bm + row) * ci + gcol) = o;
     }
 }
 
-bool readout_x3_supported(int nwm, int ci, int C) { return nwm >= 1 && nwm <= 4 && ci % 256 == 0 && C >= 2 && C <= 48 && C % 2 == 0; }
+bool readout_x3_supported(int nwm, int ci, int C) { return nwm >= 1 && nwm <= 4 && ci % 128 == 0 && C >= 2 && C <= 48 && C % 2 == 0; }
 
 // zpart: [nslab][B*32*nwm][C] split-K partials of the last conv (written by launch_gemm_clip_x3 with lastpk/zpart);
-// WTpk: x3_pack of the last conv's transposed weights ([ci][C], k zero-padded to 64)
+// WTpk: x3_pack of the last conv's transposed weights ([ci][C], k zero-padded to 64);
+// img: scratch of readout_x3_image_bytes(B, nwm) bytes (dL/dZ of the last block as A fragments)
+size_t readout_x3_image_bytes(int B, int nwm) { return (size_t)B * 2 * 3 * (2 * nwm) * 1024; }
 void launch_readout_x3(const float* hin, int ci, const float* zpart, int nslab, const float* bias, const void* WTpk,
                        const float* rstd_prev, const float* target, float* pred, float* loss, float* best_loss, int* improved,
                        int* step, float* dZ, int B, int nwm, int Tp, int C, int nbits, int loss_kind, hipStream_t st,
-                       const float* loss_add) {
-    const int G = ci / 256, nc = (C + 15) / 16;
+                       const float* loss_add, void* img) {
+    const int G = ci / 128, nc = (C + 15) / 16;
     const size_t slab_stride = (size_t)B * 32 * nwm * C;
-#define RK(M_, N_) hipLaunchKernelGGL((readout_x3_kernel<M_, N_>), dim3(B * G), dim3(512), 0, st, hin, ci, zpart, nslab, slab_stride, \
-                                      bias, (const u32x4*)WTpk, rstd_prev, target, pred, loss, best_loss, improved, step, dZ, Tp, C, \
-                                      nbits, loss_kind, G, B * G, loss_add)
-#define RN(M_) switch (nc) { case 1: RK(M_, 1); break; case 2: RK(M_, 2); break; case 3: RK(M_, 3); break; default: RK(M_, 4); break; }
+#define RH(M_, N_) hipLaunchKernelGGL((readout_head_x3_kernel<M_, N_>), dim3(B), dim3(512), 0, st, zpart, nslab, slab_stride, bias,    \
+                                      target, pred, loss, best_loss, improved, step, (unsigned char*)img, Tp, C, nbits, loss_kind, \
+                                      loss_add)
+#define RN(M_) switch (nc) { case 1: RH(M_, 1); break; case 2: RH(M_, 2); break; case 3: RH(M_, 3); break; default: RH(M_, 4); break; }
     switch (nwm) { case 1: RN(1) break; case 2: RN(2) break; case 3: RN(3) break; default: RN(4) break; }
 #undef RN
-#undef RK
+#undef RH
+#define RGK(M_) hipLaunchKernelGGL((readout_grad_x3_kernel<M_>), dim3(B * G), dim3(512), 0, st, hin, ci, (const unsigned char*)img, \
+                                   (const u32x4*)WTpk, rstd_prev, dZ, Tp, G, B * G)
+    switch (nwm) { case 1: RGK(1); break; case 2: RGK(2); break; case 3: RGK(3); break; default: RGK(4); break; }
+#undef RGK
 }
 
 }  // namespace aware

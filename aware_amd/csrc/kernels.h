@@ -127,7 +127,8 @@ bool readout_x3_supported(int nwm, int ci, int C);
 void launch_readout_x3(const float* hin, int ci, const float* zpart, int nslab, const float* bias, const void* WTpk,
                        const float* rstd_prev, const float* target, float* pred, float* loss, float* best_loss, int* improved,
                        int* step, float* dZ, int B, int nwm, int Tp, int C, int nbits, int loss_kind, hipStream_t st,
-                       const float* loss_add = nullptr);
+                       const float* loss_add, void* img);
+size_t readout_x3_image_bytes(int B, int nwm);      // scratch `img` of launch_readout_x3 (must not alias dZ)
 // mel block: InstanceNorm over time, per-clip GlobalStandardize, AvgPool(2,2)
 void launch_mel_norm_fwd(const float* xm, const int* frame_off, const int* pool_off, float* x0, float* stats,
                          float* gstat, float* part, int pstride, int B, int max_frames, hipStream_t st);
