@@ -267,6 +267,30 @@ __global__ __launch_bounds__(64 * NW, (RG <= 3 && NW == 8) ? 4 : 2) void gemm_cl
     // ---- epilogue: lane holds rows m*16 + 4*kg + e (e = 0..3) of columns cb + n*16 + r16 ----
     const int cb = bn + wave * (16 * NTW) + r16;
     const float invT = 1.0f / (float)Tp;
+    if (EPI == X3_PLAIN && NTW == 1 && (ldc & 3) == 0) {
+        // The tile leaves in ROW-MAJOR order (16 bytes per lane, half a wave = one 512-byte row segment), not in the
+        // accumulator's layout (4 rows x 64 bytes per wave instruction, which streams at about half the rate: measured on
+        // the read-out kernel, 3.0 vs 6 TB/s).  The staging LDS is free now; pitch 132 floats keeps both sides conflict-free.
+        float (*T)[132] = reinterpret_cast<float (*)[132]>(lds);
+        const float bv = bias ? bias[cb] : 0.f;
+        __syncthreads();                                // every wave has left the K loop
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) T[16 * m + 4 * kg + e][16 * wave + r16] = acc[m][0][e] + bv;
+        __syncthreads();
+        const int c4 = (lane & 31) * 4, rr = 2 * wave + (lane >> 5);
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int row = rr + 16 * j;
+            float4 o = *reinterpret_cast<const float4*>(&T[row][c4]);
+            if (row >= Tp) o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bm + row < Mrows) *reinterpret_cast<float4*>(C + (size_t)(bm + row) * ldc + bn + c4) = o;
+        }
+        return;
+    }
+    // (the forward / backward epilogues keep the accumulator-layout stores: behind the K loop of a second resident workgroup
+    //  they are hidden -- the row-major form measured the same time on the three conv blocks)
 #pragma unroll
     for (int n = 0; n < NTW; ++n) {
         const int col = cb + n * 16;
