@@ -639,47 +639,70 @@ __global__ __launch_bounds__(512, 4) void gemm_ragged_x3_kernel(const float* __r
         g0 += ng;
     }
     if (single) return;
-#ifdef X3_ABLATE_PASS2
-    return;
-#endif
-    // ---- pass 2: this lane's column of every row, read back from the raw tile it wrote ----
+    // ---- pass 2 over the raw tile this workgroup wrote: ROW-MAJOR (lane = 4 consecutive columns, half a wave = one 512-byte
+    // row segment), the per-column statistics handed over through LDS.  In the accumulator's layout (the lane that wrote a
+    // value reads it back: 4 rows x 64 bytes per wave instruction) this pass streamed at about half the rate. ----
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, kg = lane >> 4;
     const int col = bn + wave * 16 + r16;
     const float invT = 1.0f / (float)Tp;
     const int npad = 32 * G;
+    float* cstat = reinterpret_cast<float*>(x3_dyn_lds);           // [2][128]; the staging memory is free now
+    __syncthreads();                                                // ... once every wave has left its last chunk
     if (EPI == X3_FWD) {
-        const float mean = st1;
         const float rs = 1.0f / sqrtf(st2 * invT + 1e-5f);
-        if (kg == 0) rstd_clip[col] = rs;
-        for (int r = 4 * kg; r < npad; r += 16) {
-            float z[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) z[e] = C[(size_t)(row0 + r + e) * ldc + col];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float u = (z[e] - mean) * rs;
-                C[(size_t)(row0 + r + e) * ldc + col] = (r + e < Tp) ? (u > 0.f ? u : 0.2f * u) : 0.f;
-            }
-        }
+        if (kg == 0) { rstd_clip[col] = rs; cstat[wave * 16 + r16] = st1; cstat[128 + wave * 16 + r16] = rs; }
     } else {
         float s1 = st1, s2 = st2;
         s1 += __shfl_xor(s1, 16);
         s1 += __shfl_xor(s1, 32);
         s2 += __shfl_xor(s2, 16);
         s2 += __shfl_xor(s2, 32);
-        const float m1 = s1 * invT, m2 = s2 * invT, rs = rstd_clip[col];
-        for (int r = 4 * kg; r < npad; r += 16) {
-            float du[4], av[4];
+        if (kg == 0) { cstat[wave * 16 + r16] = s1 * invT; cstat[128 + wave * 16 + r16] = s2 * invT; }
+    }
+    __syncthreads();                                                // statistics in LDS; every wave's raw rows are visible
+    const int c4 = (lane & 31) * 4, rr = 2 * wave + (lane >> 5);
+    const float4 q0 = *reinterpret_cast<const float4*>(cstat + c4), q1 = *reinterpret_cast<const float4*>(cstat + 128 + c4);
+    float* const Cw = C + (size_t)row0 * ldc + bn + c4;
+    if (EPI == X3_FWD) {
+        for (int r0 = rr; r0 < npad; r0 += 64) {                    // four rows per lane in flight
+            float4 z[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                du[e] = C[(size_t)(row0 + r + e) * ldc + col];
-                av[e] = act[(size_t)(row0 + r + e) * ldc + col];
+            for (int j = 0; j < 4; ++j) z[j] = *reinterpret_cast<const float4*>(Cw + (size_t)min(r0 + 16 * j, npad - 1) * ldc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = r0 + 16 * j;
+                if (r >= npad) continue;
+                auto f = [&](float v, float mean, float rs) {
+                    const float u = (v - mean) * rs;
+                    return (r < Tp) ? (u > 0.f ? u : 0.2f * u) : 0.f;
+                };
+                *reinterpret_cast<float4*>(Cw + (size_t)r * ldc) =
+                    make_float4(f(z[j].x, q0.x, q1.x), f(z[j].y, q0.y, q1.y), f(z[j].z, q0.z, q1.z), f(z[j].w, q0.w, q1.w));
+            }
+        }
+    } else {
+        const float4 rs4 = *reinterpret_cast<const float4*>(rstd_clip + bn + c4);
+        const float* const Aw = act + (size_t)row0 * ldc + bn + c4;
+        for (int r0 = rr; r0 < npad; r0 += 64) {
+            float4 du[4], av[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const size_t o = (size_t)min(r0 + 16 * j, npad - 1) * ldc;
+                du[j] = *reinterpret_cast<const float4*>(Cw + o);
+                av[j] = *reinterpret_cast<const float4*>(Aw + o);
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float uv = av[e] > 0.f ? av[e] : av[e] * 5.0f;
-                C[(size_t)(row0 + r + e) * ldc + col] = (r + e < Tp) ? rs * (du[e] - m1 - uv * m2) : 0.f;
+            for (int j = 0; j < 4; ++j) {
+                const int r = r0 + 16 * j;
+                if (r >= npad) continue;
+                auto f = [&](float d, float a, float rs, float m1, float m2) {
+                    const float uv = a > 0.f ? a : a * 5.0f;
+                    return (r < Tp) ? rs * (d - m1 - uv * m2) : 0.f;
+                };
+                *reinterpret_cast<float4*>(Cw + (size_t)r * ldc) =
+                    make_float4(f(du[j].x, av[j].x, rs4.x, q0.x, q1.x), f(du[j].y, av[j].y, rs4.y, q0.y, q1.y),
+                                f(du[j].z, av[j].z, rs4.z, q0.z, q1.z), f(du[j].w, av[j].w, rs4.w, q0.w, q1.w));
             }
         }
     }
