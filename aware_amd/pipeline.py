@@ -208,3 +208,45 @@ def synthetic_ragged_clips(seconds, rate: int, seeds=None, device="cuda"):
         bits[i] = torch.randint(0, 2, (20,), generator=g, device=device, dtype=torch.int32)
         o += n
     return rt.Ragged(audio, lengths), bits
+
+
+def run_folder(folder, embedder, detector, attacks=(), watermark_length: int = 20, seed: int | None = None,
+               pattern: str = "*.wav") -> dict:
+    """The reference's harness loop over a folder of audio files (`scripts/test.py:52-106`): load mono at the native
+    rate, resample to 16 kHz when needed, embed a random watermark, detect, then apply every attack on its own and detect
+    again.  Returns `{"files": [...], "orig": [BER % per file], attack.name: [BER % per file], ..., "snr_db": [...]}` --
+    the `rec` dictionary of the reference (BER in percent, `metrics/audio.py:8-17`) plus the SNR of each watermarked file.
+    Files are WAV (`aware_amd.utils.audio.io`); clips of one native rate are embedded as one ragged batch; a file the
+    reference would refuse (too short for the STFT) is skipped with its error recorded under "skipped"."""
+    from pathlib import Path
+    from .utils.audio import io
+    rng = np.random.default_rng(seed)
+    paths = sorted(Path(folder).glob(pattern))
+    rec = {"files": [], "orig": [], "snr_db": [], "skipped": []}
+    by_rate = {}
+    for p in paths:
+        try:
+            x, sr = io.load(str(p), sr=None, mono=True)
+        except ValueError as e:
+            rec["skipped"].append((p.name, str(e)))
+            continue
+        if len(x) * 16000 // sr <= 512:                      # torch.stft's reflect padding needs more than n_fft / 2 samples
+            rec["skipped"].append((p.name, "clip too short"))
+            continue
+        by_rate.setdefault(sr, []).append((p.name, x))
+    for sr, items in sorted(by_rate.items()):
+        names = [n for n, _ in items]
+        audio = rt.Ragged.from_list([x for _, x in items])
+        bits = torch.as_tensor(rng.integers(0, 2, size=(len(items), watermark_length)), dtype=torch.int32, device="cuda")
+        pipe = WatermarkPipeline(embedder, detector, attacks=[])
+        res = pipe.run(audio, bits, input_rate=sr, report_snr=True)
+        wm_bits, _ = pipe._detect_bits(res.watermarked)
+        rec["files"] += names
+        rec["orig"] += (100.0 * (wm_bits != bits).float().mean(dim=1)).cpu().tolist()
+        rec["snr_db"] += res.snr_db.cpu().tolist()
+        for a in attacks:
+            attacked = a.apply_batch(res.watermarked, 16000)
+            a_bits, _ = pipe._detect_bits(attacked)
+            rec.setdefault(a.name, [])
+            rec[a.name] += (100.0 * (a_bits != bits).float().mean(dim=1)).cpu().tolist()
+    return rec

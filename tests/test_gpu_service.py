@@ -381,3 +381,24 @@ def test_pipeline_snr_and_44k_back_end(models):
     n = min(len(ref_out), len(a))
     ref_snr = 10 * np.log10(np.mean(ref_out[:n].astype(np.float64) ** 2) / np.mean((ref_out[:n].astype(np.float64) - a[:n]) ** 2))
     assert abs(snr[0] - ref_snr) < 1.0, (snr[0], ref_snr)
+
+
+def test_run_folder_harness(tmp_path):
+    """The reference's harness loop over a folder (scripts/test.py:52-106) on WAV files: two 16 kHz clips (one PCM16, one
+    float), one 44.1 kHz clip (front-end resampling), one file that is too short; BER per file clean and per attack."""
+    from aware_amd.utils.models import load
+    from aware_amd.utils.audio import io
+    from aware_amd import attacks as A
+    from aware_amd.pipeline import run_folder
+    rng = np.random.default_rng(11)
+    io.write_wav(tmp_path / "a.wav", (0.1 * rng.standard_normal(16000)).astype(np.float32), 16000)
+    io.write_wav(tmp_path / "b.wav", (0.1 * rng.standard_normal(24000)).astype(np.float32), 16000, subtype="FLOAT")
+    io.write_wav(tmp_path / "c.wav", (0.1 * rng.standard_normal(44100)).astype(np.float32), 44100, subtype="FLOAT")
+    io.write_wav(tmp_path / "short.wav", np.zeros(300, dtype=np.float32), 16000)
+    emb, det = load()
+    rec = run_folder(tmp_path, emb, det, attacks=[A.PCMBitDepthConversion(16), A.LowPassFilter()], seed=3)
+    assert sorted(rec["files"]) == ["a.wav", "b.wav", "c.wav"]
+    assert [n for n, _ in rec["skipped"]] == ["short.wav"]
+    assert rec["orig"] == [0.0, 0.0, 0.0]                                   # BER in percent, clean path: bit-exact
+    assert rec["pcm_16"] == [0.0, 0.0, 0.0] and rec["low_pass"] == [0.0, 0.0, 0.0]
+    assert all(np.isfinite(v) and v > 10.0 for v in rec["snr_db"])
