@@ -598,14 +598,26 @@ static int clip_tile_groups(const aware_batch* b) {
     return (g >= 1 && g <= 4) ? g : 0;
 }
 
+// fewer clips than this: the per-clip mel front kernel would leave most CUs idle; the two-launch form wins
+constexpr int kMelFrontMinClips = 192;
+
 // forward through the network; mag [NF][256] -> act[last], pred
 static int det_forward(const aware_detector* d, const aware_batch* b, const float* mag, DetBufs& o, hipStream_t st,
                        int pipe = 0, bool skip_last = false) {
-    gemm_plain(pipe, mag, kFS, d->melT, kFS, d->melTpk, nullptr, o.xm, 128, b->NF, 128, kFS, st);
-    LAUNCHCHK(); PROF(K_GEMM);
-    launch_mel_norm_fwd(o.xm, b->d_frame_off, b->d_pool_off, o.x0, o.mstats, o.gstat, o.mpart, o.mstride, b->B,
-                        b->max_frames, st);
-    LAUNCHCHK(); PROF(K_MELNORM);
+    bool same_T = true;
+    for (int i = 1; i < b->B; ++i) same_T = same_T && b->T[i] == b->T[0];
+    if (pipe == 0 && d->melTpk && same_T && b->B >= kMelFrontMinClips && mel_front_x3_supported(b->T[0], kFS, kFS)) {
+        // uniform batch that fills the chip with one workgroup per clip: the whole mel block in one launch
+        launch_mel_front_x3(mag, kFS, d->melTpk, b->d_frame_off, b->d_pool_off, o.xm, o.x0, o.mstats, o.gstat, b->B, b->T[0],
+                            kFS, st);
+        LAUNCHCHK(); PROF(K_MELNORM);
+    } else {
+        gemm_plain(pipe, mag, kFS, d->melT, kFS, d->melTpk, nullptr, o.xm, 128, b->NF, 128, kFS, st);
+        LAUNCHCHK(); PROF(K_GEMM);
+        launch_mel_norm_fwd(o.xm, b->d_frame_off, b->d_pool_off, o.x0, o.mstats, o.gstat, o.mpart, o.mstride, b->B,
+                            b->max_frames, st);
+        LAUNCHCHK(); PROF(K_MELNORM);
+    }
     const float* x = o.x0;
     const int nwm = clip_tile_groups(b);
     o.tail = 0;

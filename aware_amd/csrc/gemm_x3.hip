@@ -898,6 +898,105 @@ void launch_gemm_clip_x3(const float* A, int lda, const void* Bpk, const float* 
 #undef XK
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Mel front end of the detector for a uniform batch of clips of at most 192 frames, ONE launch, one workgroup per clip:
+// mel projection (K = 256 band bins, N = 128) on the bf16x3 tile GEMM with all of the clip's rows in one tile, then
+// InstanceNorm1d(128) over time, GlobalStandardize over the clip, AvgPool1d(2, 2) in the epilogue (the statistics are
+// in-register sums, two shuffles and one exchange through LDS).  Replaces the plain mel GEMM + mel_norm_clip_fwd_kernel
+// (24 + 11.5 us at B = 256: both latency-bound) and the 25 MB round trip of the mel tile between them; the raw mel tile
+// is still written once, for the backward kernel.
+//   reference: detection/modules/mel.py:185-201, multibit_detector_net.py:50,126-131, modules/globalStandardize.py:16-21
+// ---------------------------------------------------------------------------------------------------
+template <int RG>
+__global__ __launch_bounds__(512, 2) void mel_front_x3_kernel(const float* __restrict__ mag, int lda, const u32x4* __restrict__ Bpk,
+                                                               const int* __restrict__ frame_off, const int* __restrict__ pool_off,
+                                                               float* __restrict__ xm, float* __restrict__ x0,
+                                                               float* __restrict__ stats, float* __restrict__ gstat, int K) {
+    constexpr int MT = 2 * RG;
+    constexpr int FRAG = 1024;
+    constexpr int BUF = 2 * 3 * MT * FRAG;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
+    __shared__ float red8[8];
+    const int b = blockIdx.x;
+    const int f0 = frame_off[b], T = frame_off[b + 1] - f0, Tp = T / 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kg = lane >> 4;
+    f32x4 acc[MT][1];
+    x3_tile_gemm<RG, 8>(mag, lda, Bpk, K, f0, 0, lds, acc, T);         // rows beyond T read row T-1 again; masked below
+    const int c = wave * 16 + r16;
+    const float fT = (float)T;
+    float s = 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (m * 16 + 4 * kg + e < T) s += acc[m][0][e];
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    const float mu = s / fT;
+    float q = 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (m * 16 + 4 * kg + e < T) { const float d = acc[m][0][e] - mu; q += d * d; }
+    q += __shfl_xor(q, 16);
+    q += __shfl_xor(q, 32);
+    const float M2 = q;
+    const float rs = 1.0f / sqrtf(M2 / fT + 1e-5f);                    // biased var, eps 1e-5 (InstanceNorm1d)
+    // GlobalStandardize: unbiased std of the normalised tile (its mean is 0): sum over channels of rs^2 M2
+    float su = (kg == 0) ? rs * rs * M2 : 0.f;
+    su = wave_sum(su);
+    __syncthreads();                                                   // every wave has left the K loop (LDS is reused below)
+    if (lane == 0) red8[wave] = su;
+    // the raw mel tile, for the backward kernel: row-major through LDS (pitch 132)
+    float (*Tm)[132] = reinterpret_cast<float (*)[132]>(lds);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Tm[16 * m + 4 * kg + e][c] = acc[m][0][e];
+    __syncthreads();
+    const float suu = ((red8[0] + red8[1]) + (red8[2] + red8[3])) + ((red8[4] + red8[5]) + (red8[6] + red8[7]));
+    const float n = fT * 128.f;
+    const float gs = sqrtf(suu / (n - 1.f));
+    const float ginv = 1.0f / (gs + 1e-8f);
+    if (kg == 0) { float* stp = stats + ((size_t)b * 128 + c) * 4; stp[0] = mu; stp[1] = rs; stp[2] = M2; stp[3] = 0.f; }
+    if (tid == 0) { gstat[b * 4 + 0] = ginv; gstat[b * 4 + 1] = gs; gstat[b * 4 + 2] = n; gstat[b * 4 + 3] = fT; }
+    const int c4 = (lane & 31) * 4, rr = 2 * wave + (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const int row = rr + 16 * j;
+        if (row < T) *reinterpret_cast<float4*>(xm + (size_t)(f0 + row) * 128 + c4) = *reinterpret_cast<const float4*>(&Tm[row][c4]);
+    }
+    __syncthreads();                                                   // the tile has been read: the buffer takes the pooled tile
+    // pooled rows: the frame pair (2 tp, 2 tp + 1) is the register pair (e, e + 1) of one lane
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int tp = (m * 16 + 4 * kg) / 2 + h;
+            const float u0 = (acc[m][0][2 * h] - mu) * rs, u1 = (acc[m][0][2 * h + 1] - mu) * rs;
+            Tm[tp][c] = tp < Tp ? 0.5f * (u0 * ginv + u1 * ginv) : 0.f;                 // AvgPool1d(2, 2)
+        }
+    __syncthreads();
+    const int Tpad = (Tp + 31) & ~31;
+    float* o = x0 + (size_t)pool_off[b] * 128;
+    for (int row = rr; row < Tpad; row += 16)          // (rows past the tile -- Tpad can exceed 16 RG -- are padding: zeros)
+        *reinterpret_cast<float4*>(o + (size_t)row * 128 + c4) =
+            row < 8 * MT ? *reinterpret_cast<const float4*>(&Tm[row][c4]) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+bool mel_front_x3_supported(int T, int K, int lda) { return T >= 2 && T <= 192 && K % 64 == 0 && lda % 4 == 0; }
+void launch_mel_front_x3(const float* mag, int lda, const void* melTpk, const int* frame_off, const int* pool_off, float* xm,
+                         float* x0, float* stats, float* gstat, int B, int T, int K, hipStream_t st) {
+#define MF(R_) hipLaunchKernelGGL((mel_front_x3_kernel<R_>), dim3(B), dim3(512), 0, st, mag, lda, (const u32x4*)melTpk, frame_off,  \
+                                  pool_off, xm, x0, stats, gstat, K)
+    const int rg = (T + 31) / 32;
+    switch (rg) { case 1: MF(1); break; case 2: MF(2); break; case 3: MF(3); break; case 4: MF(4); break; case 5: MF(5); break;
+                  default: MF(6); break; }
+#undef MF
+}
+
 bool gemm_clip_x3_supported(int nwm, int N, int K, int lda) {
     return nwm >= 1 && nwm <= 4 && N % 128 == 0 && K % 64 == 0 && lda % 4 == 0;
 }

@@ -110,6 +110,12 @@ void launch_gemm_clip(const float* A, int lda, const float* Bt, int ldb, const f
 size_t x3_packed_bytes(int N, int K);
 void x3_pack(const float* Wt, int N, int K, uint16_t* out);      // host: [N][K] f32 -> fragment-ordered bf16 planes
 bool gemm_clip_x3_supported(int nwm, int N, int K, int lda);
+// mel projection + InstanceNorm + GlobalStandardize + AvgPool of a UNIFORM batch of clips of T <= 192 frames in one launch
+// (one workgroup per clip): xm [NF][128] raw mel tile (kept for the backward), x0 pooled tile, stats / gstat as
+// launch_mel_norm_fwd leaves them
+bool mel_front_x3_supported(int T, int K, int lda);
+void launch_mel_front_x3(const float* mag, int lda, const void* melTpk, const int* frame_off, const int* pool_off, float* xm,
+                         float* x0, float* stats, float* gstat, int B, int T, int K, hipStream_t st);
 // lastpk/zpart (forward epilogue only): also emit the split-K partials [N/128][B*32*nwm][CL] of the next, last conv
 // block (x3_pack of its weights zero-padded to a multiple of 16 rows), consumed by launch_readout_x3
 void launch_gemm_clip_x3(const float* A, int lda, const void* Bpk, const float* bias, float* C, int ldc, int B, int nwm,

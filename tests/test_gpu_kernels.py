@@ -618,3 +618,22 @@ def test_ragged_fused_conv_blocks(rt, plan, det, O):
     s2.begin(solo.pack([pairs[5][0]]), torch.from_numpy(wm[5:6]).cuda())
     s2.gradient()
     assert abs(float(s2.loss.cpu()[0]) - float(l4[5])) < 2e-6
+
+
+@pytest.mark.parametrize("n,B", [(16000, 194), (48000, 192), (33000, 193), (41600, 192)])
+def test_mel_front_fused_matches_two_launch(rt, plan, det, n, B):
+    """Uniform batches of >= 192 clips of <= 192 frames run the mel block (projection, InstanceNorm, GlobalStandardize,
+    pooling) in ONE launch (mel_front_x3_kernel); smaller batches keep the mel GEMM + mel_norm kernels.  Same clips
+    through both: raw detector outputs agree to float32 rounding (the mel values are bit-identical, the statistics are
+    summed in a different order).  Geometries: 63, 188, 129 (16 RG < padded pooled rows) and 163 frames."""
+    rng = np.random.default_rng(n)
+    clips = [(0.1 * rng.standard_normal(n)).astype(np.float32) for _ in range(B)]
+    full = rt.Batch([n] * B)
+    v_full = rt.detect(plan, det, full, full.pack(clips)).cpu().numpy()
+    half = B // 2
+    part = []
+    for lo, hi in ((0, half), (half, B)):
+        bb = rt.Batch([n] * (hi - lo))
+        part.append(rt.detect(plan, det, bb, bb.pack(clips[lo:hi])).cpu().numpy())
+    v_two = np.concatenate(part)
+    assert np.max(np.abs(v_full - v_two)) < 2e-6, np.max(np.abs(v_full - v_two))
