@@ -252,11 +252,35 @@ __global__ __launch_bounds__(64 * NW, (RG <= 3 && NW == 8) ? 4 : 2) void gemm_cl
     constexpr int BUF = 2 * 3 * MT * FRAG;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
 
+    // Blocks b and b + 8 share an XCD (observed round-robin placement; speed only).  An XCD takes a contiguous range of clips and
+    // walks it slab-group-major: `sg` column slabs at a time whose packed weights (sg * 128 * K * 6 bytes) fit its 4 MB L2
+    // together with the activation rows in flight, all clips of the range for that group, then the next group.  Clip-major
+    // order streamed all 6.3 MB of a 1024 x 1024 layer through the L2 for every clip (PMC: 565 MB fetched per launch for 206 MB
+    // of operands); this order fetches the weights once per XCD and the activation rows once per group.
     int id = blockIdx.x;
-    if ((ntiles & 7) == 0) id = (id & 7) * (ntiles >> 3) + (id >> 3);
-    const int clip = id / tiles_n;
+    int clip, slab_;
+    if ((ntiles & 7) == 0) {
+        const int x = id & 7, j = id >> 3, R = ntiles >> 3;          // XCD, index inside its range, workgroups per XCD
+        const int nclip = R / tiles_n;                                // clips per XCD (ntiles = clips * tiles_n, clips % 8 == 0 here
+        if (nclip * tiles_n == R && nclip > 0) {                     //  whenever the batch size is a multiple of 8)
+            int sg = (int)(3355443u / (unsigned)(128 * K * 6));      // slabs whose weights fit 3.2 MB
+            sg = sg < 1 ? 1 : (sg > tiles_n ? tiles_n : sg);
+            while (tiles_n % sg) --sg;
+            const int per_group = nclip * sg;
+            const int grp = j / per_group, r = j % per_group;
+            clip = x * nclip + r / sg;
+            slab_ = grp * sg + r % sg;
+        } else {
+            id = x * R + j;
+            clip = id / tiles_n;
+            slab_ = id % tiles_n;
+        }
+    } else {
+        clip = id / tiles_n;
+        slab_ = id % tiles_n;
+    }
     const int bm = clip * 32 * RG;
-    const int bn = (id % tiles_n) * 128;
+    const int bn = slab_ * 128;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kg = lane >> 4;
