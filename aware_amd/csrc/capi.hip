@@ -601,12 +601,16 @@ static int clip_tile_groups(const aware_batch* b) {
 // fewer clips than this: the per-clip mel front kernel would leave most CUs idle; the two-launch form wins
 constexpr int kMelFrontMinClips = 192;
 
+static bool mel_front_applies(const aware_detector* d, const aware_batch* b, int pipe) {
+    bool same_T = true;
+    for (int i = 1; i < b->B; ++i) same_T = same_T && b->T[i] == b->T[0];
+    return pipe == 0 && d->melTpk && same_T && b->B >= kMelFrontMinClips && mel_front_x3_supported(b->T[0], kFS, kFS);
+}
+
 // forward through the network; mag [NF][256] -> act[last], pred
 static int det_forward(const aware_detector* d, const aware_batch* b, const float* mag, DetBufs& o, hipStream_t st,
                        int pipe = 0, bool skip_last = false) {
-    bool same_T = true;
-    for (int i = 1; i < b->B; ++i) same_T = same_T && b->T[i] == b->T[0];
-    if (pipe == 0 && d->melTpk && same_T && b->B >= kMelFrontMinClips && mel_front_x3_supported(b->T[0], kFS, kFS)) {
+    if (mel_front_applies(d, b, pipe)) {
         // uniform batch that fills the chip with one workgroup per clip: the whole mel block in one launch
         launch_mel_front_x3(mag, kFS, d->melTpk, b->d_frame_off, b->d_pool_off, o.xm, o.x0, o.mstats, o.gstat, b->B, b->T[0],
                             kFS, st);
@@ -743,6 +747,8 @@ static int det_forward_backward(const aware_detector* d, const aware_batch* b, c
     bool dz_ready = false;      // dA already holds dL/dZ of layer l (fused into the producing kernel)
     int l_top = nl - 1;         // first layer the backward loop below still has to differentiate
     bool last_k64 = false;      // dL/dZ of the last block was written with a row pitch of 64
+    bool mel_bwd_done = false;
+    const bool mel_fused = mel_front_applies(d, b, pipe);
     if (fused_readout) {
         launch_readout_x3(db.act[nl - 2], d->ch[nl - 1], db.zpart, d->ch[nl - 1] / 128, d->bias[nl - 1], d->lastTpk,
                           db.rstd[nl - 2], G.target, db.pred, G.loss, G.best_loss, G.improved, G.step, dA, b->B,
@@ -805,6 +811,11 @@ static int det_forward_backward(const aware_detector* d, const aware_batch* b, c
             launch_gemm_ragged_x3(dA, co, d->wTpk[l], nullptr, dB, ci, b->B, b->d_frame_off, b->d_pool_off, b->d_order, ci, co, 2,
                                   db.rstd[l - 1], db.act[l - 1], st);
             LAUNCHCHK(); PROF(K_GEMM_X3_BWD);
+        } else if (l == 0 && mel_fused && dz_ready && !G.wgrad && d->wTpk[0] && co % 64 == 0 && ci == 128) {
+            // large uniform batch: block 0's data gradient and the backward of the mel block's normalisations in one launch
+            launch_mel_back_x3(dA, co, d->wTpk[0], b->d_frame_off, b->d_pool_off, db.xm, db.mstats, db.gstat, b->B, b->T[0], co, st);
+            LAUNCHCHK(); PROF(K_MELNORM);
+            mel_bwd_done = true;
         } else {
             gemm_plain(pipe, dA, co, d->wT[l], co, d->wTpk[l], nullptr, dB, ci, b->NP, ci, co, st);
             dz_ready = false;
@@ -812,9 +823,11 @@ static int det_forward_backward(const aware_detector* d, const aware_batch* b, c
         }
         float* t = dA; dA = dB; dB = t;
     }
-    launch_mel_norm_bwd(dA, db.xm, b->d_frame_off, b->d_pool_off, db.mstats, db.gstat, db.mpart, db.mstride, b->B,
-                        b->max_frames, st);
-    LAUNCHCHK(); PROF(K_MELNORM);
+    if (!mel_bwd_done) {
+        launch_mel_norm_bwd(dA, db.xm, b->d_frame_off, b->d_pool_off, db.mstats, db.gstat, db.mpart, db.mstride, b->B,
+                            b->max_frames, st);
+        LAUNCHCHK(); PROF(K_MELNORM);
+    }
     gemm_plain(pipe, db.xm, 128, d->melB, 128, d->melBpk, nullptr, G.gmag, kFS, b->NF, kFS, 128, st);
     LAUNCHCHK(); PROF(K_GEMM);
     return AWARE_OK;

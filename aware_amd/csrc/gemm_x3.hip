@@ -1021,6 +1021,91 @@ void launch_mel_front_x3(const float* mag, int lda, const void* melTpk, const in
 #undef MF
 }
 
+// The backward counterpart of mel_front_x3_kernel, same batches: the data gradient of the first conv block (K = its output
+// channels, N = 128 mel channels; the clip's pooled rows as one tile) with the backward of AvgPool, GlobalStandardize and
+// InstanceNorm1d(128) in the epilogue.  xm holds the raw mel tile on entry and dL/d(mel) on exit (as
+// mel_norm_clip_bwd_kernel leaves it); stats / gstat as the forward kernel wrote them.  Replaces the plain data-gradient GEMM
+// + mel_norm_clip_bwd_kernel and the round trip of the pooled gradient between them.
+//   reference: what loss.backward() derives for multibit_detector_net.py:126-131
+template <int RG>
+__global__ __launch_bounds__(512, 2) void mel_back_x3_kernel(const float* __restrict__ dZ, int lda,
+                                                                            const u32x4* __restrict__ Bpk,
+                                                                            const int* __restrict__ frame_off,
+                                                                            const int* __restrict__ pool_off,
+                                                                            float* __restrict__ xm, const float* __restrict__ stats,
+                                                                            const float* __restrict__ gstat, int K) {
+    constexpr int MT = 2 * RG;
+    constexpr int FRAG = 1024;
+    constexpr int BUF = 2 * 3 * MT * FRAG;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
+    __shared__ float red8[2][8];
+    const int b = blockIdx.x;
+    const int f0 = frame_off[b], T = frame_off[b + 1] - f0, Tp = T / 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int Tpad = (Tp + 31) & ~31;
+    f32x4 acc[MT][1];
+    // (an odd T has one more frame than pooled pairs: the tile may be taller than the clip's pooled rows; reads are clamped)
+    x3_tile_gemm<RG, 8>(dZ, lda, Bpk, K, pool_off[b], 0, lds, acc, Tpad);
+    const int c = wave * 16 + r16;
+    const float* stp = stats + ((size_t)b * 128 + c) * 4;
+    const float mu = stp[0], rs = stp[1], M2 = stp[2];
+    const float ginv = gstat[b * 4 + 0], gs = gstat[b * 4 + 1], n = gstat[b * 4 + 2];
+    float* x = xm + (size_t)f0 * 128 + c;
+    float ua[MT][4], ub[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                   // loads first, from clamped rows; masked below
+            const int t = 2 * (m * 16 + 4 * kg + e);
+            ua[m][e] = x[(size_t)min(t, T - 1) * 128];
+            ub[m][e] = x[(size_t)min(t + 1, T - 1) * 128];
+        }
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool pair = m * 16 + 4 * kg + e < Tp;
+            const float dv = pair ? 0.5f * acc[m][0][e] : 0.f;        // d(avg pool): half the pooled gradient to each frame
+            acc[m][0][e] = dv;
+            ua[m][e] = (ua[m][e] - mu) * rs;                          // u
+            ub[m][e] = (ub[m][e] - mu) * rs;
+            if (pair) { a1 += 2.f * dv; a2 += dv * ua[m][e] + dv * ub[m][e]; }
+        }
+    a1 += __shfl_xor(a1, 16); a1 += __shfl_xor(a1, 32);
+    a2 += __shfl_xor(a2, 16); a2 += __shfl_xor(a2, 32);
+    const float D1 = a1, D2 = a2;
+    const float w1 = wave_sum(kg == 0 ? D1 : 0.f), w2 = wave_sum(kg == 0 ? D2 : 0.f);
+    if (lane == 0) { red8[0][wave] = w1; red8[1][wave] = w2; }
+    __syncthreads();
+    const float sa = ((red8[0][0] + red8[0][1]) + (red8[0][2] + red8[0][3])) + ((red8[0][4] + red8[0][5]) + (red8[0][6] + red8[0][7]));
+    const float sb = ((red8[1][0] + red8[1][1]) + (red8[1][2] + red8[1][3])) + ((red8[1][4] + red8[1][5]) + (red8[1][6] + red8[1][7]));
+    const float fT = (float)T;
+    const float mdv = sa / n;
+    const float Q = (gs > 0.f) ? sb * ginv * ginv / ((n - 1.f) * gs) : 0.f;
+    const float m1 = ginv * (D1 / fT - mdv);
+    const float m2 = (ginv * D2 - Q * rs * rs * M2) / fT;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int t = 2 * (m * 16 + 4 * kg + e);
+            const float dv = acc[m][0][e];
+            if (t < T) { const float u = ua[m][e]; x[(size_t)t * 128] = rs * (((dv - mdv) * ginv - u * Q) - m1 - u * m2); }
+            if (t + 1 < T) { const float u = ub[m][e]; x[(size_t)(t + 1) * 128] = rs * (((dv - mdv) * ginv - u * Q) - m1 - u * m2); }
+        }
+}
+
+void launch_mel_back_x3(const float* dZ, int lda, const void* wTpk, const int* frame_off, const int* pool_off, float* xm,
+                        const float* stats, const float* gstat, int B, int T, int K, hipStream_t st) {
+#define MB(R_) hipLaunchKernelGGL((mel_back_x3_kernel<R_>), dim3(B), dim3(512), 0, st, dZ, lda, (const u32x4*)wTpk, frame_off,     \
+                                  pool_off, xm, stats, gstat, K)
+    const int rg = ((T + 1) / 2 + 31) / 32;            // rows cover the unpaired last frame of an odd T
+    switch (rg) { case 1: MB(1); break; case 2: MB(2); break; default: MB(3); break; }
+#undef MB
+}
+
 bool gemm_clip_x3_supported(int nwm, int N, int K, int lda) {
     return nwm >= 1 && nwm <= 4 && N % 128 == 0 && K % 64 == 0 && lda % 4 == 0;
 }

@@ -116,6 +116,10 @@ bool gemm_clip_x3_supported(int nwm, int N, int K, int lda);
 bool mel_front_x3_supported(int T, int K, int lda);
 void launch_mel_front_x3(const float* mag, int lda, const void* melTpk, const int* frame_off, const int* pool_off, float* xm,
                          float* x0, float* stats, float* gstat, int B, int T, int K, hipStream_t st);
+// backward of the same block for the same batches: data gradient of the first conv block (dZ [NP][K], wTpk = x3_pack of its
+// transposed weights [128][K]) + AvgPool / GlobalStandardize / InstanceNorm backward; xm: raw mel in, dL/d(mel) out
+void launch_mel_back_x3(const float* dZ, int lda, const void* wTpk, const int* frame_off, const int* pool_off, float* xm,
+                        const float* stats, const float* gstat, int B, int T, int K, hipStream_t st);
 // lastpk/zpart (forward epilogue only): also emit the split-K partials [N/128][B*32*nwm][CL] of the next, last conv
 // block (x3_pack of its weights zero-padded to a multiple of 16 rows), consumed by launch_readout_x3
 void launch_gemm_clip_x3(const float* A, int lda, const void* Bpk, const float* bias, float* C, int ldc, int B, int nwm,
