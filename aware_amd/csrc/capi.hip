@@ -760,8 +760,7 @@ static int det_forward_backward(const aware_detector* d, const aware_batch* b, c
     } else if (db.tail) {
         // ragged batch on the bf16x3 pipe: dL/dZ of the last block with a pitch of 64 (zero K padding), so that its data
         // gradient runs on the ragged conv kernel with the previous block's InstanceNorm + LeakyReLU backward fused
-        last_k64 = !nwm && pipe == 0 && !G.wgrad && nl >= 2 && d->lastTpk && d->ch[nl] <= 64 &&
-                   gemm_clip_x3_supported(1, d->ch[nl - 1], 64, 64);
+        last_k64 = !nwm && pipe == 0 && !G.wgrad && nl >= 2 && d->lastTpk && d->ch[nl] <= 64 && d->ch[nl - 1] % 128 == 0;
         launch_tail(db.zpart, kTailSplit, (size_t)b->NP * d->ch[nl], d->bias[nl - 1], b->d_frame_off, b->d_pool_off,
                     G.target, db.pred, G.loss, G.best_loss, G.improved, dA, G.step, G.loss_kind, d->nbits, b->B,
                     b->max_frames / 2, st, G.loss_add, last_k64 ? 64 : 0);
@@ -802,8 +801,8 @@ static int det_forward_backward(const aware_detector* d, const aware_batch* b, c
             }
         } else if (l == nl - 1 && last_k64) {
             dz_ready = true;
-            launch_gemm_ragged_x3(dA, 64, d->lastTpk, nullptr, dB, ci, b->B, b->d_frame_off, b->d_pool_off, b->d_order, ci, 64, 2,
-                                  db.rstd[l - 1], db.act[l - 1], st);
+            launch_readout_grad_ragged_x3(db.act[l - 1], ci, dA, d->lastTpk, db.rstd[l - 1], dB, b->d_frame_off, b->d_pool_off,
+                                          b->d_order, b->B, st);
             LAUNCHCHK(); PROF(K_GEMM_X3_BWD);
         } else if (!nwm && pipe == 0 && l > 0 && ci >= 128 && d->wTpk[l] && gemm_clip_x3_supported(1, ci, co, co)) {
             // ragged batch: data-gradient GEMM + backward of block l-1's InstanceNorm + LeakyReLU in one launch

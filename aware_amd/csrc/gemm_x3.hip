@@ -1453,6 +1453,162 @@ __global__ __launch_bounds__(512, RG <= 3 ? 4 : 2) void readout_grad_x3_kernel(c
     }
 }
 
+// The same gradient kernel for RAGGED batches (clips of any length): dZl is dL/dZ of the last block as float32 rows with a
+// pitch of 64 (tail_kernel, zero K padding); a workgroup owns 128 columns of one clip and walks the clip's pooled rows in
+// chunks of 96.  A clip longer than one chunk is swept twice -- column sums of the InstanceNorm backward first, results
+// second -- recomputing the (K = 64) products instead of writing raw values and reading them back: the kernel only streams
+// the activation in (twice) and the gradient out (once), row-major.  Replaces the K = 64 launch of the ragged conv kernel
+// (raw tile + second pass in the accumulator layout: 230 us on config 5).
+__global__ __launch_bounds__(512, 4) void readout_grad_ragged_x3_kernel(const float* __restrict__ hin, int ci,
+                                                                         const float* __restrict__ dZl,
+                                                                         const u32x4* __restrict__ WTpk,
+                                                                         const float* __restrict__ rstd_prev, float* __restrict__ dZ,
+                                                                         const int* __restrict__ frame_off,
+                                                                         const int* __restrict__ pool_off,
+                                                                         const int* __restrict__ order, int G) {
+    constexpr int RG = 3, MT = 2 * RG, FRAG = 1024, KSC = 2;
+    constexpr int IMG = KSC * 3 * MT * FRAG;
+    constexpr int TBYTES = 32 * RG * 132 * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_buf[TBYTES > IMG ? TBYTES : IMG];
+    __shared__ float red[2][8][128];
+    float (*T)[132] = reinterpret_cast<float (*)[132]>(lds_buf);
+    const int id = blockIdx.x;
+    const int clip = order ? order[id / G] : id / G, g = id % G;
+    const int Tp = (frame_off[clip + 1] - frame_off[clip]) / 2;
+    if (Tp < 1) return;
+    const int row0 = pool_off[clip], npad = (Tp + 31) & ~31;
+    const int nchunk = (npad + 32 * RG - 1) / (32 * RG);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kg = lane >> 4;
+    const float invT = 1.0f / (float)Tp;
+    const int ntb = g * 8 + wave;                       // the 16-column tile of this wave
+    u32x4 bw[KSC][3];
+#pragma unroll
+    for (int t = 0; t < KSC; ++t)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bw[t][p] = WTpk[(((size_t)ntb * KSC + t) * 3 + p) * 64 + lane];
+    const int c4 = (lane & 31) * 4, rr = 2 * wave + (lane >> 5);
+    const size_t gcol = (size_t)g * 128 + c4;
+    const float4 rsp = *reinterpret_cast<const float4*>(rstd_prev + (size_t)clip * ci + gcol);
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1, m1 = s1, m2 = s1;
+    // always two sweeps (statistics, then results): keeping a chunk's values in registers across the reduction for the
+    // single-chunk case costs the 24 VGPRs that decide between one and two workgroups per CU; a short clip's second read of
+    // its 49 KB of activation rows comes from L2
+    constexpr int nsweep = 2;
+    for (int sweep = 0; sweep < nsweep; ++sweep) {
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int rbase = 32 * RG * ch;                     // first row of the chunk inside the clip
+            const int rows = min(32 * RG, npad - rbase);        // allocated rows under this chunk (a multiple of 32)
+            // dL/dZ of the last block for these rows -> bf16x3 A fragments (k = channel) in LDS
+            if (ch || sweep) __syncthreads();                   // the previous round's tile has been read
+            for (int i = tid; i < 32 * RG * 16; i += 512) {     // one float4 = 4 consecutive channels of one row
+                const int r = i >> 4, q = i & 15, c = 4 * q;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < rows) v = *reinterpret_cast<const float4*>(dZl + (size_t)(row0 + rbase + r) * 64 + c);
+                unsigned a0, a1, a2, b0, b1, b2;
+                split_pair(v.x, v.y, a0, a1, a2);
+                split_pair(v.z, v.w, b0, b1, b2);
+                unsigned char* d = lds_buf + (size_t)((c >> 5) * 3 * MT + (r >> 4)) * FRAG + ((r & 15) + 16 * ((c & 31) >> 3)) * 16 + (c & 7) * 2;
+                *reinterpret_cast<uint2*>(d) = make_uint2(a0, b0);
+                *reinterpret_cast<uint2*>(d + MT * FRAG) = make_uint2(a1, b1);
+                *reinterpret_cast<uint2*>(d + 2 * MT * FRAG) = make_uint2(a2, b2);
+            }
+            __syncthreads();
+            f32x4 acc[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < KSC; ++t) {
+                bf16x8 b[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(bf16x8, bw[t][p]);
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    bf16x8 a[RG][3];
+#pragma unroll
+                    for (int m = 0; m < RG; ++m)
+#pragma unroll
+                        for (int p = 0; p < 3; ++p)
+                            a[m][p] = *reinterpret_cast<const bf16x8*>(lds_buf + (size_t)((t * 3 + p) * MT + hf * RG + m) * FRAG + lane * 16);
+#pragma unroll
+                    for (int term = 0; term < 6; ++term) {
+                        const int pa = term == 0 ? 2 : (term == 1 || term == 3) ? 1 : 0;
+                        const int pb = term == 2 ? 2 : (term == 1 || term == 4) ? 1 : 0;
+#pragma unroll
+                        for (int m = 0; m < RG; ++m)
+                            acc[hf * RG + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][pa], b[pb], acc[hf * RG + m], 0, 0, 0);
+                    }
+                }
+            }
+            // activation rows of the chunk, row-major (requested here, behind the products: before them they cost the
+            // registers that keep two workgroups on a CU; the barriers and the transpose below cover most of the latency)
+            float4 hv[MT];
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+                hv[j] = *reinterpret_cast<const float4*>(hin + (size_t)(row0 + rbase + min(rr + 16 * j, rows - 1)) * ci + gcol);
+            __syncthreads();                                    // every wave has read its fragments: the buffer becomes the tile
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) T[16 * m + 4 * kg + e][16 * wave + r16] = acc[m][e];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                const int rl = rr + 16 * j, row = rbase + rl;   // row inside the chunk / the clip
+                const float4 gacc = *reinterpret_cast<const float4*>(&T[rl][c4]);
+                const bool valid = row < Tp;
+                float4 d, u;
+                auto one = [&](float gv, float av, float& dd, float& uu) {
+                    uu = valid ? (av > 0.f ? av : av * 5.0f) : 0.f;                         // invert LeakyReLU(0.2)
+                    dd = valid ? gv * (av > 0.f ? 1.f : 0.2f) : 0.f;
+                };
+                one(gacc.x, hv[j].x, d.x, u.x);
+                one(gacc.y, hv[j].y, d.y, u.y);
+                one(gacc.z, hv[j].z, d.z, u.z);
+                one(gacc.w, hv[j].w, d.w, u.w);
+                if (sweep == 0) {
+                    s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
+                    s2.x += d.x * u.x; s2.y += d.y * u.y; s2.z += d.z * u.z; s2.w += d.w * u.w;
+                } else if (rl < rows) {
+                    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (valid) {
+                        o.x = rsp.x * (d.x - m1.x - u.x * m2.x);
+                        o.y = rsp.y * (d.y - m1.y - u.y * m2.y);
+                        o.z = rsp.z * (d.z - m1.z - u.z * m2.z);
+                        o.w = rsp.w * (d.w - m1.w - u.w * m2.w);
+                    }
+                    *reinterpret_cast<float4*>(dZ + (size_t)(row0 + row) * ci + gcol) = o;
+                }
+            }
+            if (sweep == 0 && ch == nchunk - 1) {
+                // column sums: the two row halves of the wave, then the eight waves
+                s1.x += __shfl_xor(s1.x, 32); s1.y += __shfl_xor(s1.y, 32); s1.z += __shfl_xor(s1.z, 32); s1.w += __shfl_xor(s1.w, 32);
+                s2.x += __shfl_xor(s2.x, 32); s2.y += __shfl_xor(s2.y, 32); s2.z += __shfl_xor(s2.z, 32); s2.w += __shfl_xor(s2.w, 32);
+                if (lane < 32) {
+                    *reinterpret_cast<float4*>(&red[0][wave][c4]) = s1;
+                    *reinterpret_cast<float4*>(&red[1][wave][c4]) = s2;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int w = 0; w < 8; ++w) {
+                    const float4 p1 = *reinterpret_cast<const float4*>(&red[0][w][c4]), p2 = *reinterpret_cast<const float4*>(&red[1][w][c4]);
+                    m1.x += p1.x; m1.y += p1.y; m1.z += p1.z; m1.w += p1.w;
+                    m2.x += p2.x; m2.y += p2.y; m2.z += p2.z; m2.w += p2.w;
+                }
+                m1.x *= invT; m1.y *= invT; m1.z *= invT; m1.w *= invT;
+                m2.x *= invT; m2.y *= invT; m2.z *= invT; m2.w *= invT;
+            }
+        }
+    }
+}
+
+void launch_readout_grad_ragged_x3(const float* hin, int ci, const float* dZl, const void* WTpk, const float* rstd_prev, float* dZ,
+                                   const int* frame_off, const int* pool_off, const int* order, int B, hipStream_t st) {
+    const int G = ci / 128;
+    hipLaunchKernelGGL(readout_grad_ragged_x3_kernel, dim3(B * G), dim3(512), 0, st, hin, ci, dZl, (const u32x4*)WTpk, rstd_prev, dZ,
+                       frame_off, pool_off, order, G);
+}
+
 bool readout_x3_supported(int nwm, int ci, int C) { return nwm >= 1 && nwm <= 4 && ci % 128 == 0 && C >= 2 && C <= 48 && C % 2 == 0; }
 
 // zpart: [nslab][B*32*nwm][C] split-K partials of the last conv (written by launch_gemm_clip_x3 with lastpk/zpart);

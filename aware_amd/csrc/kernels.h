@@ -139,6 +139,10 @@ void launch_readout_x3(const float* hin, int ci, const float* zpart, int nslab, 
                        int* step, float* dZ, int B, int nwm, int Tp, int C, int nbits, int loss_kind, hipStream_t st,
                        const float* loss_add, void* img);
 size_t readout_x3_image_bytes(int B, int nwm);      // scratch `img` of launch_readout_x3 (must not alias dZ)
+// ragged batches: data gradient of the last conv from dZl (float32 rows, pitch 64, zero K padding: launch_tail with ldz = 64)
+// with the backward of the previous block's InstanceNorm + LeakyReLU; ci % 128 == 0, last conv of at most 64 channels
+void launch_readout_grad_ragged_x3(const float* hin, int ci, const float* dZl, const void* WTpk, const float* rstd_prev, float* dZ,
+                                   const int* frame_off, const int* pool_off, const int* order, int B, hipStream_t st);
 // mel block: InstanceNorm over time, per-clip GlobalStandardize, AvgPool(2,2)
 void launch_mel_norm_fwd(const float* xm, const int* frame_off, const int* pool_off, float* x0, float* stats,
                          float* gstat, float* part, int pstride, int B, int max_frames, hipStream_t st);
