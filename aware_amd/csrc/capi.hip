@@ -181,7 +181,7 @@ extern "C" int aware_batch_create(aware_batch** out, int B, const int* n_samples
     // arithmetic and are only worth it while the chip would otherwise idle
     // (measured, 3 s clips, us synthesis / adjoint: B = 256: 16 66/66, 12 65/64, 8 77/75; B = 128: 12 43/47, 8 40/42, 6 39/42,
     // 4 51/52; B = 64: 8 31/30, 6 28/28, 4 28/28)
-    for (int rb : {16, 12, 8, 6, 4}) {
+    for (int rb : {12, 8, 6, 4}) {          // (16 never measured better than 12)
         long runs = 0;
         for (int i = 0; i < B; ++i) runs += (n_samples[i] / kHop + rb - 1) / rb;
         // the staged adjoint folds the reflect pads inside the first / last segment: keep those at >= 3 blocks
@@ -225,11 +225,14 @@ extern "C" int aware_batch_create(aware_batch** out, int B, const int* n_samples
     b->NS = kHop * (b->NF - B);
     b->pstride = max_pc;
     {
-        // frames per analysis run: the longest R in [4, 16] that still gives 4096 waves; for a uniform batch then the nearest
+        // (runs longer than 12 frames measured slower even when the chip has waves to spare: B = 256 x 3 s, analysis / adjoint
+        //  67 / 118 us at R = 12 against 69 / 136 at R = 16)
+        constexpr int kAnalysisMaxRun = 12;
+        // frames per analysis run: the longest R in [4, 12] that still gives 4096 waves; for a uniform batch then the nearest
         // shorter R whose run count per clip is a multiple of the waves of a workgroup (measurements: dsp_stream.hip)
         auto total_runs = [&](int r) { long t = 0; for (int i = 0; i < B; ++i) t += (b->T[i] + r - 1) / r; return t; };
         int R = 4;
-        for (int cand = 16; cand >= 4; --cand)
+        for (int cand = kAnalysisMaxRun; cand >= 4; --cand)
             if (total_runs(cand) >= 4096) { R = cand; break; }
         bool same = true;
         for (int i = 1; i < B; ++i) same = same && b->T[i] == b->T[0];
