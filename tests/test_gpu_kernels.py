@@ -413,16 +413,16 @@ def test_fused_path_on_another_detector_geometry(rt, plan, O):
 # round 2: the tolerance box, the 3 s golden trajectory and the 44.1 kHz golden on the HIP path
 # (tolerances = 3x the drift measured on MI355X by tests/tools/measure_drift.py, recorded in profiles/r02_drift.json)
 # ---------------------------------------------------------------------------------------------------------
-# Measured on MI355X against the reference's recorded run, twice in round 2 (profiles/r02_drift.json before and
-# profiles/r02_drift_b.json after the last kernel changes; worst of the 1 s and 3 s golden clips and of the two matrix
+# Measured on MI355X against the reference's recorded run, three times in round 2 (profiles/r02_drift.json,
+# r02_drift_b.json, r02_drift_c.json: after the DSP, the GEMM and the read-out kernel changes; worst of the 1 s and 3 s golden clips and of the two matrix
 # pipes): |loss - reference loss| is 1.2e-7 at step 0, <= 1.9e-3 over the first 20 steps (the 3 s clip has a LeakyReLU
-# argument 2e-7 from its kink), <= 5.7e-3 at any of the 400 steps; best loss 1.0e-3 on the default pipe; raw detector
+# argument 2e-7 from its kink), <= 5.7e-3 at any of the 400 steps; best loss 0.1e-3 ... 2.0e-3 on the default pipe; raw detector
 # outputs of the watermarked clip 0.6e-2 ... 2.6e-2 (the trajectory is chaotic: any change of summation order re-draws
-# these -- the 1 s clip gave 2.6e-2 in the first measurement and 0.6e-2 in the second); waveform rel-L2 7.2e-2.
+# these -- the 1 s clip gave 2.6e-2, 0.6e-2 and 1.1e-2 in the three measurements); waveform rel-L2 7.4e-2.
 # Two CPU runs of the reference itself differ by ~1e-3 at step 400.
 # Tolerances below = 3x the constants here: the measured maxima of the default (bf16x3) pipe; for `raw` 3x the constant
-# is 1.7x the largest value seen.
-DRIFT = {"step0": 2.4e-7, "first20": 1.9e-3, "any": 5.7e-3, "best": 1.1e-3, "out_rel_l2": 0.072, "raw": 1.5e-2}
+# is 2.3x the largest value seen.
+DRIFT = {"step0": 2.4e-7, "first20": 1.9e-3, "any": 5.7e-3, "best": 2.0e-3, "out_rel_l2": 0.075, "raw": 2.0e-2}
 
 
 @pytest.mark.parametrize("lengths,seeds", [([16000], [1]), ([48000, 16000, 23456], [0, 1, 2])])
