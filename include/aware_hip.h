@@ -262,7 +262,10 @@ int aware_decimate_interp(const float* in, const int* off, const int* len, int B
 /* scipy.signal.lfilter (LowPassFilter / HighPassFilter :400-455) and filtfilt (RandomBandstop
  * :324-356) in f64.  b, a: dev f64 [B][ncoef] (a[0] == 1); zi: dev f64 [B][ncoef-1] (filtfilt only).
  * out is f64 when out_f64 != 0 (the reference returns float64 from lfilter), else f32.
- * scratch (filtfilt): dev f64 [B][max_len + 6*ncoef]. */
+ * scratch (filtfilt): dev f64 [B][max_len + 6*ncoef].  2 <= ncoef <= 12.  A filtfilt clip must be longer than the
+ * padding of 3*ncoef samples (scipy raises for such a clip; the host binding does the same, the kernel only stays inside
+ * its buffers).  One workgroup per clip, parallel in time (128 chunks chained with a double-double state transition):
+ * results agree with scipy's sequential recurrence to the rounding of that recurrence itself. */
 int aware_iir(const float* in, const int* off, const int* len, int B, int max_len, void* out, int out_f64,
               const double* b, const double* a, const double* zi, int ncoef, int filtfilt,
               void* scratch, void* stream);
