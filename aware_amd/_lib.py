@@ -129,6 +129,7 @@ SIGNATURES = {
     "aware_x3_packed_bytes": (_sz, [_i, _i]),
     "aware_x3_pack": (_i, [_vp, _i, _i, _vp]),
     "aware_gemm_clip": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "aware_gemm_clip_last": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "aware_gemm_nt": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
 }
 

@@ -1436,6 +1436,18 @@ extern "C" int aware_gemm_clip(const float* A, int lda, const float* Bt, int ldb
     return AWARE_OK;
 }
 
+// the forward conv block whose epilogue also emits the split-K partials of the NEXT (skinny, CL <= 48 channels) conv:
+// the kernel the embed loop runs for block 2 (X3_FWD_LAST).  Test / roofline entry; always the throughput kernel.
+extern "C" int aware_gemm_clip_last(const float* A, int lda, const void* Bpk, const float* bias, float* C, int ldc, int B, int Tp,
+                                    int N, int K, float* rstd_out, const void* lastpk, float* zpart, int CL, void* stream) {
+    if (!A || !Bpk || !C || !rstd_out || !lastpk || !zpart || B < 1 || Tp < 1 || Tp > 128 || CL < 2 || CL > 48) return AWARE_E_BADARG;
+    const int nwm = (Tp + 31) / 32;
+    if (!gemm_clip_x3_supported(nwm, N, K, lda)) return AWARE_E_BADARG;
+    launch_gemm_clip_x3(A, lda, Bpk, bias, C, ldc, B, nwm, Tp, N, K, 1, rstd_out, nullptr, (hipStream_t)stream, lastpk, zpart, CL);
+    LAUNCHCHK();
+    return AWARE_OK;
+}
+
 extern "C" int aware_gemm_nt(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc,
                              int M, int N, int K, void* stream) {
     if (!A || !Bt || !C || M < 1 || N < 1 || K < 4 || (K & 3) || (lda & 3) || (ldb & 3)) return AWARE_E_BADARG;

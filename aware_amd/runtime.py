@@ -437,6 +437,26 @@ def gemm_clip(a: torch.Tensor, bt: torch.Tensor, bias, B: int, Tp: int, epi: int
     return c, rstd
 
 
+def gemm_clip_last(a: torch.Tensor, bt: torch.Tensor, bias, w_last: torch.Tensor, B: int, Tp: int):
+    """The forward conv block + split-K partials of the next (skinny) conv, as the embed loop runs block 2
+    (aware_gemm_clip_last).  a: [B*32*ceil(Tp/32), K]; bt: [N, K]; w_last: [CL, N].  Returns (C, rstd, zpart[N/128, M, CL])."""
+    lib = load_library()
+    M, K = a.shape
+    N = bt.shape[0]
+    CL = w_last.shape[0]
+    clp = 16 * ((CL + 15) // 16)
+    wl = torch.zeros((clp, N), dtype=torch.float32)
+    wl[:CL] = w_last.detach().cpu().float()
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    rstd = torch.zeros((B, N), dtype=torch.float32, device=a.device)
+    zpart = torch.zeros((N // 128, M, CL), dtype=torch.float32, device=a.device)
+    pk, pkl = x3_pack(bt), x3_pack(wl)                 # (named: both must stay allocated until the launch has been enqueued)
+    check(lib.aware_gemm_clip_last(_ptr(a), a.stride(0), _ptr(pk), _ptr(bias), _ptr(c), N, B, Tp, N, K, _ptr(rstd),
+                                   _ptr(pkl), _ptr(zpart), CL, _stream()), "aware_gemm_clip_last")
+    torch.cuda.current_stream().synchronize()
+    return c, rstd, zpart
+
+
 # ---------------------------------------------------------------------------------------------
 # ragged signal batches and the attack-stage entry points
 # ---------------------------------------------------------------------------------------------

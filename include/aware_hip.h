@@ -320,6 +320,12 @@ int aware_x3_pack(const float* host_wt, int N, int K, void* host_out);
 int aware_gemm_clip(const float* A, int lda, const float* Bt, int ldb, const void* Bpk, const float* bias, float* C,
                     int ldc, int B, int Tp, int N, int K, int epi, float* rstd_io, const float* act, int mode,
                     void* stream);
+/* The same forward block (epi 1, bf16 matrix-pipe kernel) as the embed loop runs it for the block in front of the skinny last
+ * conv (detection/multibit_detector_net.py:58-70: 1024 -> 40): besides C and rstd_out the epilogue writes the split-K
+ * partials of the NEXT conv, zpart [N/128][B*32*ceil(Tp/32)][CL] with  sum_s zpart[s] = C * Wlast^T  (no bias).
+ * lastpk: dev, aware_x3_pack of Wlast [16*ceil(CL/16)][N] (rows beyond CL zero).  2 <= CL <= 48.  Test / roofline entry. */
+int aware_gemm_clip_last(const float* A, int lda, const void* Bpk, const float* bias, float* C, int ldc, int B, int Tp,
+                         int N, int K, float* rstd_out, const void* lastpk, float* zpart, int CL, void* stream);
 
 #ifdef __cplusplus
 }

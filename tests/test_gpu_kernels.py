@@ -75,8 +75,19 @@ def _block_reference(a, w, bias, act, rstd, B, RP, Tp, epi):
     return rstd.double()[:, None, :] * (du - du.mean(1, keepdim=True) - u * (du * u).mean(1, keepdim=True))
 
 
-@pytest.mark.parametrize("B,Tp,N,K,epi", [(5, 94, 512, 128, 1), (3, 94, 1024, 512, 1), (4, 94, 1024, 1024, 2), (2, 31, 128, 64, 0),
-                                          (3, 64, 256, 192, 1), (2, 128, 128, 320, 2), (9, 50, 384, 128, 0)])
+# grids below 128 workgroups (B * N/128) run gemm_clip_x3_small_kernel, the latency variant; the others run
+# gemm_clip_x3_kernel<RG, EPI, 8>, the throughput kernel the bench times: plain tile walk when B * N/128 is not a multiple
+# of 8 (B = 21), slab-group-major walk otherwise; RG = 1..4 (Tp = 31, 63, 94, 128); the bench's own three forward shapes
+# and two data-gradient shapes at B = 256 / 64 / 40.
+X3_SMALL = [(5, 94, 512, 128, 1), (3, 94, 1024, 512, 1), (4, 94, 1024, 1024, 2), (2, 31, 128, 64, 0),
+            (3, 64, 256, 192, 1), (2, 128, 128, 320, 2), (9, 50, 384, 128, 0)]
+X3_LARGE = [(40, 94, 512, 128, 1), (256, 94, 512, 128, 1), (24, 94, 1024, 512, 1), (64, 94, 1024, 512, 1),
+            (16, 94, 1024, 1024, 2), (64, 94, 1024, 1024, 2), (64, 94, 512, 1024, 2), (21, 94, 1024, 1024, 1),
+            (21, 94, 1024, 1024, 2), (40, 94, 512, 128, 0), (72, 31, 512, 128, 1), (32, 63, 1024, 512, 2),
+            (32, 128, 1024, 256, 1), (19, 128, 1024, 256, 2), (64, 94, 1024, 1024, 1)]
+
+
+@pytest.mark.parametrize("B,Tp,N,K,epi", X3_SMALL + X3_LARGE)
 def test_gemm_clip_x3(rt, B, Tp, N, K, epi):
     """The bf16 three-way-split conv block against fp64, beside the f32-MFMA kernel on the same inputs:
     its error must be at the level of a k-ordered f32 fma chain (f32-equivalent), for every epilogue."""
@@ -109,6 +120,39 @@ def test_gemm_clip_x3(rt, B, Tp, N, K, epi):
     tol = 4e-6 * max(1.0, K / 256)
     assert e32 < tol and ex3 < tol, (e32, ex3)
     assert ex3 < 2.0 * e32 + 2e-7, (e32, ex3)          # never meaningfully worse than the f32 pipe
+
+
+@pytest.mark.parametrize("B,Tp,N,K,CL", [(16, 94, 1024, 1024, 40), (21, 94, 1024, 1024, 40), (64, 94, 1024, 1024, 40),
+                                         (32, 63, 1024, 512, 40), (40, 94, 512, 256, 32), (128, 31, 1024, 128, 16)])
+def test_gemm_clip_last_partials(rt, B, Tp, N, K, CL):
+    """gemm_clip_x3_kernel<RG, X3_FWD_LAST, 8> -- block 2 of the embed loop: conv + InstanceNorm + LeakyReLU AND the split-K
+    partials of the skinny last conv from the output tile -- against fp64 (conv1d.py:38-42, multibit_detector_net.py:58-70)."""
+    RP = 32 * ((Tp + 31) // 32)
+    g = torch.Generator().manual_seed(B + Tp + N + K + CL)
+    a = torch.randn(B * RP, K, generator=g)
+    a.view(B, RP, K)[:, Tp:] = 0
+    w = torch.randn(N, K, generator=g) * torch.exp2(torch.randint(-6, 4, (N, 1), generator=g).float()) / K ** 0.5
+    bias = torch.randn(N, generator=g) * 0.1
+    wl = torch.randn(CL, N, generator=g) * torch.exp2(torch.randint(-4, 3, (CL, 1), generator=g).float()) / N ** 0.5
+    ref = _block_reference(a, w, bias, None, None, B, RP, Tp, 1)                      # [B, Tp, N] fp64
+    c, rs, zp = rt.gemm_clip_last(a.cuda(), w, bias.cuda(), wl, B, Tp)
+    c = c.cpu().view(B, RP, N)
+    assert RP == Tp or c[:, Tp:].abs().max().item() == 0.0
+    scale = ref.abs().amax(dim=(0, 1), keepdim=True).clamp_min(1e-30)
+    err = ((c[:, :Tp].double() - ref).abs() / scale).max().item()
+    tol = 4e-6 * max(1.0, K / 256)
+    assert err < tol, err
+    z = (a.double() @ w.double().T).view(B, RP, N)[:, :Tp] + bias.double()
+    ref_rs = 1.0 / torch.sqrt(z.var(1, unbiased=False) + 1e-5)
+    assert ((rs.cpu().double() - ref_rs).abs() / ref_rs).max().item() < 2e-5
+    # the partials: their sum over the N/128 slabs is the next conv (without bias) of the block's output
+    zsum = zp.cpu().double().sum(0).view(B, RP, CL)
+    zref = ref @ wl.double().T                                                        # [B, Tp, CL]
+    zs = zref.abs().amax(dim=(0, 1), keepdim=True).clamp_min(1e-30)
+    ez = ((zsum[:, :Tp] - zref).abs() / zs).max().item()
+    print(f"block output err {err:.2e}; last-conv partial-sum err {ez:.2e}")
+    assert ez < 4e-6 * max(1.0, N / 256) + 8 * err, ez
+    assert RP == Tp or zsum[:, Tp:].abs().max().item() == 0.0
 
 
 def test_x3_split_is_exact(rt):
@@ -672,3 +716,108 @@ def test_large_uniform_batch_gradient_matches_split_batches(rt, plan, det, B):
     # are ordered differently (the same sensitivity as in test_first_iteration_matches_oracle): a finite, isolated difference
     assert np.median(rel) < 5e-6
     assert int((rel > 2e-5).sum()) <= 3 and rel.max() < 5e-2, rel.max()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# round 3: the kernels the bench times, directly under the oracle
+# ---------------------------------------------------------------------------------------------------------
+def _oracle_first_iteration(O, emb, clip, wm_row):
+    a = torch.from_numpy(clip)[None]
+    mag0, phase = emb.analyse(a)
+    c0 = mag0[:, emb.band].clone().requires_grad_(True)
+    l, p = emb.forward_loss(c0, mag0, phase, torch.from_numpy(wm_row)[None])
+    l.sum().backward()
+    return float(l.detach()), p[0].detach().numpy(), c0.grad[0], _min_kink_distance(emb, mag0, phase)
+
+
+@pytest.mark.parametrize("n,B,sample", [(48000, 256, [0, 1, 31, 77, 128, 200, 254, 255]),
+                                        (48000, 200, [0, 7, 63, 100, 150, 199]),          # B % 8 != 0: plain tile walk
+                                        (16000, 192, [0, 5, 95, 96, 190, 191]),           # RG = 1 tiles
+                                        (33000, 193, [0, 64, 192])])                      # 129 frames: RG = 3, odd T
+def test_first_iteration_gradient_large_uniform_batch(rt, plan, det, O, n, B, sample):
+    """The bench's own kernels under the oracle: a uniform batch of >= 192 clips runs mel_front_x3_kernel,
+    gemm_clip_x3_kernel<RG, FWD / FWD_LAST / BWD, 8> (slab-group-major walk when B % 8 == 0), readout_head_x3_kernel,
+    readout_grad_x3_kernel and mel_back_x3_kernel.  Loss, prediction and dL/dcoef of a sample of the clips against torch
+    autograd on the oracle (multibit_embedder.py:95-111, multibit_detector_net.py:109-140, conv1d.py:38-42): 5e-5
+    relative L2, kink-aware as in test_first_iteration_gradient."""
+    pairs = [make_clip(1000 + i, n) for i in range(B)]
+    wm = np.stack([O.bits_to_bipolar(p[1]) for p in pairs]).astype(np.float32)
+    batch = rt.Batch([n] * B)
+    sess = rt.EmbedSession(plan, det, batch, use_graph=False)
+    sess.begin(batch.pack([p[0] for p in pairs]), torch.from_numpy(wm).cuda())
+    g = sess.gradient()
+    torch.cuda.synchronize()
+    g = g.cpu()
+    loss, pred = sess.loss.cpu().numpy(), sess.pred.cpu().numpy()
+    emb = O.Embedder()
+    for i in sample:
+        l, p, ref, kink = _oracle_first_iteration(O, emb, pairs[i][0], wm[i])
+        mine = g[batch.frame_offsets[i]: batch.frame_offsets[i + 1], :225].T
+        rel = (mine - ref).norm().item() / ref.norm().item()
+        print(f"B = {B}, clip {i}: loss err {abs(loss[i] - l):.1e}, pred err {np.max(np.abs(pred[i] - p)):.1e}, "
+              f"gradient rel L2 {rel:.2e}, kink {kink:.1e}")
+        assert abs(loss[i] - l) < 2e-5, (i, loss[i], l)
+        np.testing.assert_allclose(pred[i], p, atol=5e-5)
+        assert rel < (5e-5 if kink > 2e-6 else 2e-2), (i, rel, kink)
+
+
+@pytest.mark.parametrize("lengths", [[112000, 160000, 48000, 16000], [128000, 80000, 160000, 100001, 64000, 23456, 144000]])
+def test_first_iteration_gradient_long_ragged(rt, plan, det, O, lengths):
+    """Ragged batches with 4 - 10 s clips under the oracle: clips above 96 pooled frames take the chunked two-pass forward and
+    backward of gemm_ragged_x3_kernel and the two-sweep readout_grad_ragged_x3_kernel; mel block by Chan-merged partials."""
+    pairs = [make_clip(300 + i, n) for i, n in enumerate(lengths)]
+    wm = np.stack([O.bits_to_bipolar(p[1]) for p in pairs]).astype(np.float32)
+    batch = rt.Batch(lengths)
+    sess = rt.EmbedSession(plan, det, batch, use_graph=False)
+    sess.begin(batch.pack([p[0] for p in pairs]), torch.from_numpy(wm).cuda())
+    g = sess.gradient()
+    torch.cuda.synchronize()
+    g = g.cpu()
+    loss, pred = sess.loss.cpu().numpy(), sess.pred.cpu().numpy()
+    emb = O.Embedder()
+    for i in range(len(lengths)):
+        l, p, ref, kink = _oracle_first_iteration(O, emb, pairs[i][0], wm[i])
+        mine = g[batch.frame_offsets[i]: batch.frame_offsets[i + 1], :225].T
+        rel = (mine - ref).norm().item() / ref.norm().item()
+        print(f"clip {i} (n = {lengths[i]}, {batch.frames[i] // 2} pooled frames): loss err {abs(loss[i] - l):.1e}, "
+              f"gradient rel L2 {rel:.2e}, kink {kink:.1e}")
+        assert abs(loss[i] - l) < 2e-5, (i, loss[i], l)
+        np.testing.assert_allclose(pred[i], p, atol=5e-5)
+        assert rel < (5e-5 if kink > 2e-6 else 2e-2), (i, rel, kink)
+
+
+@pytest.mark.parametrize("tag,seed,n,B,slot", [("3s", 0, 48000, 256, 0), ("3s", 0, 48000, 256, 201), ("1s", 1, 16000, 192, 77)])
+def test_embed_golden_trajectory_inside_a_large_batch(rt, plan, det, O, tag, seed, n, B, slot):
+    """The reference's recorded 400-step run (embed_{1s,3s}.npz) with the golden clip travelling in slot `slot` of a uniform
+    batch of B clips, i.e. through the throughput kernels the bench times (graph replay of 16 iterations): every step's
+    loss, the best loss, the bits (exact) and the raw detector outputs within the same drift band as the single-clip test."""
+    e = np.load(os.path.join(GOLDEN, f"embed_{tag}.npz"))
+    pairs = [make_clip(5000 + i, n) for i in range(B)]
+    pairs[slot] = make_clip(seed, n)
+    wm = np.stack([O.bits_to_bipolar(p[1]) for p in pairs]).astype(np.float32)
+    batch = rt.Batch([n] * B)
+    sess = rt.EmbedSession(plan, det, batch, use_graph=True)
+    sess.begin(batch.pack([p[0] for p in pairs]), torch.from_numpy(wm).cuda())
+    mine = []
+    for _ in range(400):
+        sess.iterate(1)
+        mine.append(sess.loss[slot: slot + 1].clone())
+    mine = torch.cat(mine).cpu().numpy()
+    ref = e["losses"]
+    d = np.abs(mine - ref)
+    print(f"{tag} in slot {slot} of {B}: |loss - reference| step0 {d[0]:.2e} first20 {d[:20].max():.2e} max {d.max():.2e}")
+    assert d[0] < 3 * DRIFT["step0"] and d[:20].max() < 3 * DRIFT["first20"] and d.max() < 3 * DRIFT["any"]
+    assert abs(float(sess.best_loss.cpu()[slot]) - float(ref.min())) < 3 * DRIFT["best"]
+    rescale = torch.tensor([float(np.max(p[0])) for p in pairs], device="cuda")
+    outs = batch.unpack_out(sess.finish(rescale))
+    out_c = outs[slot].cpu().numpy()
+    step = int(e["out_step"])
+    rel = np.linalg.norm(out_c[::step] - e["out_sample"]) / np.linalg.norm(e["out_sample"])
+    assert rel < 3 * DRIFT["out_rel_l2"], rel
+    ob = rt.Batch([o.shape[0] for o in outs])
+    vals = rt.detect(plan, det, ob, torch.cat(outs)).cpu().numpy()
+    np.testing.assert_array_equal(O.decode_bits(vals[slot]), e["det_bits"])
+    assert np.max(np.abs(vals[slot] - e["raw_marked"])) < 3 * DRIFT["raw"]
+    # every clip of the batch carries its own bits
+    for i in range(B):
+        np.testing.assert_array_equal(O.decode_bits(vals[i]), pairs[i][1])
