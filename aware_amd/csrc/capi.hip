@@ -96,6 +96,10 @@ struct aware_detector {
     void* lastpk = nullptr;    // last conv, rows zero-padded to a multiple of 16 (read-out kernel)
     void* lastTpk = nullptr;   // its transpose [Cin][64], k zero-padded to 64
     void* pkmem = nullptr;
+    // the conv blocks' two operands as f16 two-term images (gemm_h2.hip: planes + per-channel inverse scales)
+    void* wh2[8] = {nullptr};
+    void* wTh2[8] = {nullptr};
+    void* h2mem = nullptr;
     float* bias[8] = {nullptr};
 };
 
@@ -500,6 +504,26 @@ static int detector_upload(aware_detector* d, const float* mel_basis, const floa
             if (o_pkT[l] != (size_t)-1) d->wTpk[l] = (char*)d->pkmem + o_pkT[l];
         }
     }
+    {
+        // f16 two-term images, packed on the device from the f32 copies just uploaded
+        size_t total2 = 0, o_h[8], o_hT[8];
+        for (int l = 0; l < n_layers; ++l) {
+            const int ci = channels[l], co = channels[l + 1];
+            o_h[l] = o_hT[l] = (size_t)-1;
+            if (gemm_clip_h2_supported(1, co, ci, ci)) { o_h[l] = total2; total2 += (h2_packed_bytes(co, ci) + 255) & ~(size_t)255; }
+            if (gemm_clip_h2_supported(1, ci, co, co)) { o_hT[l] = total2; total2 += (h2_packed_bytes(ci, co) + 255) & ~(size_t)255; }
+        }
+        if (total2) {
+            if (alloc) HIPCHK(hipMalloc(&d->h2mem, total2));
+            for (int l = 0; l < n_layers; ++l) {
+                const int ci = channels[l], co = channels[l + 1];
+                if (o_h[l] != (size_t)-1) { d->wh2[l] = (char*)d->h2mem + o_h[l]; launch_h2_pack(d->w[l], ci, co, ci, d->wh2[l], 0); }
+                if (o_hT[l] != (size_t)-1) { d->wTh2[l] = (char*)d->h2mem + o_hT[l]; launch_h2_pack(d->wT[l], co, ci, co, d->wTh2[l], 0); }
+            }
+            LAUNCHCHK();
+            HIPCHK(hipStreamSynchronize(0));
+        }
+    }
     return AWARE_OK;
 }
 
@@ -533,6 +557,7 @@ extern "C" void aware_detector_destroy(aware_detector* d) {
     if (!d) return;
     if (d->mem) (void)hipFree(d->mem);
     if (d->pkmem) (void)hipFree(d->pkmem);
+    if (d->h2mem) (void)hipFree(d->h2mem);
     delete d;
 }
 
@@ -540,7 +565,7 @@ extern "C" void aware_detector_destroy(aware_detector* d) {
 // (32-row blocks play the role of clips; plain epilogue), else on the f32-MFMA kernel.
 static void gemm_plain(int pipe, const float* A, int lda, const float* Bt, int ldb, const void* Bpk, const float* bias, float* C,
                        int ldc, int M, int N, int K, hipStream_t st) {
-    if (pipe == 0 && Bpk && gemm_clip_x3_supported(1, N, K, lda)) {
+    if (pipe != 1 && Bpk && gemm_clip_x3_supported(1, N, K, lda)) {
         // tile height: a workgroup streams its whole weight slab (6 K N/tn bytes) for its rows, so taller tiles cut the L2
         // traffic of these short-K GEMMs; keep at least two workgroups per CU's worth of tiles.  M need not be a multiple
         // of the tile height (ragged batches): the last row block is partial
@@ -563,6 +588,10 @@ struct DetBufs {
     float* pred;      // [B][nbits]
     float* zpart;     // split-K partial slabs of the last conv [kTailSplit][NP][C_last]
     int tail;         // 1: the last conv was left as partials for the fused tail kernel
+    // per-clip partial maxima [B][64] for the f16 two-term GEMM's scales: of x0 (index 0), of act[l] (index l + 1), and of
+    // the two gradient ping-pong buffers (gmax)
+    float* amax[9];
+    float* gmax[2];
 };
 constexpr int kTailSplit = 4;
 // slabs of split-K partials of the last conv: 4 from the split-K GEMM, Cin/128 from the fused forward epilogue
@@ -584,13 +613,17 @@ static void carve_det(Carver& c, const aware_batch* b, const aware_detector* d, 
     o.pred = c.take<float>((size_t)b->B * d->nbits);
     o.zpart = c.take<float>((size_t)zpart_slabs(d) * b->NP * d->ch[d->n_layers]);
     o.tail = 0;
+    for (int l = 0; l <= d->n_layers; ++l) o.amax[l] = c.take<float>((size_t)b->B * 64);
+    o.gmax[0] = c.take<float>((size_t)b->B * 64);
+    o.gmax[1] = c.take<float>((size_t)b->B * 64);
 }
 static size_t det_bytes(const aware_batch* b, const aware_detector* d) {
     size_t f = (size_t)b->NF * 128 + (size_t)b->NP * 128 + (size_t)b->B * (128 * 4 + 4 + d->nbits) +
                (size_t)b->B * ((b->max_frames + 31) / 32) * 256;
     for (int l = 0; l < d->n_layers; ++l) f += (size_t)(b->NP + b->B) * d->ch[l + 1];
     f += (size_t)zpart_slabs(d) * b->NP * d->ch[d->n_layers];
-    return f * sizeof(float) + 256 * (8 + 2 * d->n_layers);
+    f += (size_t)b->B * 64 * (d->n_layers + 3);
+    return f * sizeof(float) + 256 * (12 + 3 * d->n_layers);
 }
 
 // number of 32-row groups per clip when the fused clip-aligned GEMM applies (uniform batch,
@@ -603,20 +636,31 @@ static int clip_tile_groups(const aware_batch* b) {
 
 // fewer clips than this: the per-clip mel front kernel would leave most CUs idle; the two-launch form wins
 constexpr int kMelFrontMinClips = 192;
+// fewer workgroups than this: the latency variant of the bf16x3 kernel serves the conv block (gemm_x3.hip, kSmallGrid)
+constexpr int kH2MinGrid = 128;
 
 static bool mel_front_applies(const aware_detector* d, const aware_batch* b, int pipe) {
     bool same_T = true;
     for (int i = 1; i < b->B; ++i) same_T = same_T && b->T[i] == b->T[0];
-    return pipe == 0 && d->melTpk && same_T && b->B >= kMelFrontMinClips && mel_front_x3_supported(b->T[0], kFS, kFS);
+    return pipe != 1 && d->melTpk && same_T && b->B >= kMelFrontMinClips && mel_front_x3_supported(b->T[0], kFS, kFS);
 }
 
 // forward through the network; mag [NF][256] -> act[last], pred
 static int det_forward(const aware_detector* d, const aware_batch* b, const float* mag, DetBufs& o, hipStream_t st,
                        int pipe = 0, bool skip_last = false) {
+    // conv blocks of a uniform batch that fills the chip: the f16 two-term kernel (default pipe); its per-clip scale comes
+    // from partial maxima that the producer of each operand leaves behind (x0_max: whether o.amax[0] is current)
+    const int nwm0 = clip_tile_groups(b);
+    auto h2_fwd = [&](int l) {
+        return pipe == 0 && nwm0 && d->wh2[l] && d->ch[l + 1] >= 128 && (d->ch[l + 1] / 128) * b->B >= kH2MinGrid &&
+               gemm_clip_h2_supported(nwm0, d->ch[l + 1], d->ch[l], d->ch[l]);
+    };
+    bool cur_max = false;            // o.amax[l] holds the maxima of the current layer input
     if (mel_front_applies(d, b, pipe)) {
         // uniform batch that fills the chip with one workgroup per clip: the whole mel block in one launch
         launch_mel_front_x3(mag, kFS, d->melTpk, b->d_frame_off, b->d_pool_off, o.xm, o.x0, o.mstats, o.gstat, b->B, b->T[0],
-                            kFS, st);
+                            kFS, st, o.amax[0]);
+        cur_max = true;
         LAUNCHCHK(); PROF(K_MELNORM);
     } else {
         gemm_plain(pipe, mag, kFS, d->melT, kFS, d->melTpk, nullptr, o.xm, 128, b->NF, 128, kFS, st);
@@ -637,7 +681,20 @@ static int det_forward(const aware_detector* d, const aware_batch* b, const floa
             o.tail = 1;
         } else if (nwm && co >= 128) {
             // conv + InstanceNorm + LeakyReLU in one kernel (clip-aligned tiles)
-            if (pipe == 0 && d->wpk[l] && gemm_clip_x3_supported(nwm, co, ci, ci)) {
+            if (h2_fwd(l)) {
+                const bool emit = skip_last && l == d->n_layers - 2;   // + split-K partials of the last conv
+                if (!cur_max) { launch_clip_amax(x, ci, ci, 32 * nwm, b->B, o.amax[l], st); LAUNCHCHK(); PROF(K_MISC); }
+                const bool next_h2 = l + 1 < d->n_layers && h2_fwd(l + 1);
+                launch_gemm_clip_h2(x, ci, d->wh2[l], o.amax[l], next_h2 ? o.amax[l + 1] : nullptr, d->bias[l], o.act[l], co, b->B,
+                                    nwm, b->uniform_tp, co, ci, 1, o.rstd[l], nullptr, st, emit ? d->lastpk : nullptr,
+                                    emit ? o.zpart : nullptr, d->ch[d->n_layers]);
+                cur_max = next_h2;
+                LAUNCHCHK(); PROF(K_GEMM_X3_FWD);
+                x = o.act[l];
+                continue;
+            }
+            cur_max = false;
+            if (pipe != 1 && d->wpk[l] && gemm_clip_x3_supported(nwm, co, ci, ci)) {
                 const bool emit = skip_last && l == d->n_layers - 2;   // + split-K partials of the last conv
                 launch_gemm_clip_x3(x, ci, d->wpk[l], d->bias[l], o.act[l], co, b->B, nwm, b->uniform_tp, co, ci, 1, o.rstd[l],
                                     nullptr, st, emit ? d->lastpk : nullptr, emit ? o.zpart : nullptr, d->ch[d->n_layers]);
@@ -647,7 +704,7 @@ static int det_forward(const aware_detector* d, const aware_batch* b, const floa
                                  nullptr, st);
                 LAUNCHCHK(); PROF(K_GEMM_CLIP_FWD);
             }
-        } else if (!nwm && pipe == 0 && co >= 128 && d->wpk[l] && gemm_clip_x3_supported(1, co, ci, ci)) {
+        } else if (!nwm && pipe != 1 && co >= 128 && d->wpk[l] && gemm_clip_x3_supported(1, co, ci, ci)) {
             // ragged batch / clips longer than the uniform kernel's tile: conv + InstanceNorm + LeakyReLU in one launch,
             // clips walked in chunks of rows (gemm_ragged_x3_kernel)
             launch_gemm_ragged_x3(x, ci, d->wpk[l], d->bias[l], o.act[l], co, b->B, b->d_frame_off, b->d_pool_off, b->d_order, co, ci, 1,
@@ -740,7 +797,7 @@ static int det_forward_backward(const aware_detector* d, const aware_batch* b, c
     // one kernel for the last conv block, the BRH head, the loss, their backward and the data gradient of the last
     // conv (uniform batches, bf16x3 configuration); otherwise split-K GEMM + tail kernel + data-gradient GEMM
     const int pipe = G.pipe;
-    const bool fused_readout = G.readout == 0 && !G.wgrad && pipe == 0 && nwm && nl >= 2 && d->lastpk && G.target &&
+    const bool fused_readout = G.readout == 0 && !G.wgrad && pipe != 1 && nwm && nl >= 2 && d->lastpk && G.target &&
                                readout_x3_supported(nwm, d->ch[nl - 1], d->ch[nl]) && d->wpk[nl - 2] &&
                                gemm_clip_x3_supported(nwm, d->ch[nl - 1], d->ch[nl - 2], d->ch[nl - 2]);
     int rc = det_forward(d, b, mag, db, st, pipe, fused_readout);
@@ -752,10 +809,21 @@ static int det_forward_backward(const aware_detector* d, const aware_batch* b, c
     bool last_k64 = false;      // dL/dZ of the last block was written with a row pitch of 64
     bool mel_bwd_done = false;
     const bool mel_fused = mel_front_applies(d, b, pipe);
+    // data-gradient GEMMs of a uniform batch that fills the chip: the f16 two-term kernel; gA / gB travel with dA / dB and hold
+    // the partial maxima of the gradient in them (g_cur: whether gA is current)
+    float* gA = db.gmax[0];
+    float* gB = db.gmax[1];
+    bool g_cur = false;
+    auto h2_bwd = [&](int l) {
+        return pipe == 0 && nwm && l > 0 && d->wTh2[l] && d->ch[l] >= 128 && (d->ch[l] / 128) * b->B >= kH2MinGrid &&
+               gemm_clip_h2_supported(nwm, d->ch[l], d->ch[l + 1], d->ch[l + 1]);
+    };
     if (fused_readout) {
         launch_readout_x3(db.act[nl - 2], d->ch[nl - 1], db.zpart, d->ch[nl - 1] / 128, d->bias[nl - 1], d->lastTpk,
                           db.rstd[nl - 2], G.target, db.pred, G.loss, G.best_loss, G.improved, G.step, dA, b->B,
-                          nwm, b->uniform_tp, d->ch[nl], d->nbits, G.loss_kind, st, G.loss_add, dB);
+                          nwm, b->uniform_tp, d->ch[nl], d->nbits, G.loss_kind, st, G.loss_add, dB,
+                          h2_bwd(nl - 2) ? gA : nullptr);
+        g_cur = h2_bwd(nl - 2);
         // (dB, the other half of the gradient ping-pong, is free until the next data-gradient GEMM writes it: it holds the
         //  read-out's fragment image, readout_x3_image_bytes = 36 KB per 3 s clip, far below NP * maxc floats)
         dz_ready = true;
@@ -763,7 +831,7 @@ static int det_forward_backward(const aware_detector* d, const aware_batch* b, c
     } else if (db.tail) {
         // ragged batch on the bf16x3 pipe: dL/dZ of the last block with a pitch of 64 (zero K padding), so that its data
         // gradient runs on the ragged conv kernel with the previous block's InstanceNorm + LeakyReLU backward fused
-        last_k64 = !nwm && pipe == 0 && !G.wgrad && nl >= 2 && d->lastTpk && d->ch[nl] <= 64 && d->ch[nl - 1] % 128 == 0;
+        last_k64 = !nwm && pipe != 1 && !G.wgrad && nl >= 2 && d->lastTpk && d->ch[nl] <= 64 && d->ch[nl - 1] % 128 == 0;
         launch_tail(db.zpart, kTailSplit, (size_t)b->NP * d->ch[nl], d->bias[nl - 1], b->d_frame_off, b->d_pool_off,
                     G.target, db.pred, G.loss, G.best_loss, G.improved, dA, G.step, G.loss_kind, d->nbits, b->B,
                     b->max_frames / 2, st, G.loss_add, last_k64 ? 64 : 0);
@@ -793,7 +861,19 @@ static int det_forward_backward(const aware_detector* d, const aware_batch* b, c
         if (nwm && l > 0 && ci >= 128) {
             // data-gradient GEMM whose epilogue is the backward of block l-1's InstanceNorm+LeakyReLU
             dz_ready = true;
-            if (pipe == 0 && d->wTpk[l] && gemm_clip_x3_supported(nwm, ci, co, co)) {
+            if (h2_bwd(l)) {
+                if (!g_cur) { launch_clip_amax(dA, co, co, 32 * nwm, b->B, gA, st); LAUNCHCHK(); PROF(K_MISC); }
+                const bool next_h2 = h2_bwd(l - 1);
+                launch_gemm_clip_h2(dA, co, d->wTh2[l], gA, next_h2 ? gB : nullptr, nullptr, dB, ci, b->B, nwm, b->uniform_tp, ci, co, 2,
+                                    db.rstd[l - 1], db.act[l - 1], st);
+                g_cur = next_h2;
+                LAUNCHCHK(); PROF(K_GEMM_X3_BWD);
+                float* t = dA; dA = dB; dB = t;
+                t = gA; gA = gB; gB = t;
+                continue;
+            }
+            g_cur = false;
+            if (pipe != 1 && d->wTpk[l] && gemm_clip_x3_supported(nwm, ci, co, co)) {
                 launch_gemm_clip_x3(dA, co, d->wTpk[l], nullptr, dB, ci, b->B, nwm, b->uniform_tp, ci, co, 2,
                                     db.rstd[l - 1], db.act[l - 1], st);
                 LAUNCHCHK(); PROF(K_GEMM_X3_BWD);
@@ -807,7 +887,7 @@ static int det_forward_backward(const aware_detector* d, const aware_batch* b, c
             launch_readout_grad_ragged_x3(db.act[l - 1], ci, dA, d->lastTpk, db.rstd[l - 1], dB, b->d_frame_off, b->d_pool_off,
                                           b->d_order, b->B, st);
             LAUNCHCHK(); PROF(K_GEMM_X3_BWD);
-        } else if (!nwm && pipe == 0 && l > 0 && ci >= 128 && d->wTpk[l] && gemm_clip_x3_supported(1, ci, co, co)) {
+        } else if (!nwm && pipe != 1 && l > 0 && ci >= 128 && d->wTpk[l] && gemm_clip_x3_supported(1, ci, co, co)) {
             // ragged batch: data-gradient GEMM + backward of block l-1's InstanceNorm + LeakyReLU in one launch
             dz_ready = true;
             launch_gemm_ragged_x3(dA, co, d->wTpk[l], nullptr, dB, ci, b->B, b->d_frame_off, b->d_pool_off, b->d_order, ci, co, 2,
@@ -1012,7 +1092,7 @@ extern "C" int aware_embed_create(aware_embed** out, const aware_plan* plan, con
                                   size_t workspace_bytes, void* stream) {
     if (!out || !plan || !det || !b || !cfg || !workspace) return AWARE_E_BADARG;
     if (cfg->num_iterations < 1 || cfg->num_iterations > 4096 || cfg->loss < 0 || cfg->loss > AWARE_LOSS_PUSH_L1) return AWARE_E_BADARG;
-    if (cfg->conv_pipe < 0 || cfg->conv_pipe > 1 || cfg->readout < 0 || cfg->readout > 1) return AWARE_E_BADARG;
+    if (cfg->conv_pipe < 0 || cfg->conv_pipe > 2 || cfg->readout < 0 || cfg->readout > 1) return AWARE_E_BADARG;
     if (cfg->dsp_path < 0 || cfg->dsp_path > 1) return AWARE_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     aware_embed* e = new aware_embed();
@@ -1065,7 +1145,7 @@ extern "C" int aware_embed_create(aware_embed** out, const aware_plan* plan, con
         HIPCHK(hipMemsetAsync(e->mag, 0, nsp * sizeof(float), st));
         // only the shapes the f32 kernel will actually serve (the bf16x3 kernel takes M % 32 == 0, N % 128 == 0, K % 64 == 0)
         auto f32_shape = [&](int M, int N, int K, int lda) {
-            return !(cfg->conv_pipe == 0 && M % 32 == 0 && gemm_clip_x3_supported(1, N, K, lda));
+            return !(cfg->conv_pipe != 1 && M % 32 == 0 && gemm_clip_x3_supported(1, N, K, lda));
         };
         if (f32_shape(b->NF, 128, kFS, kFS)) gemm_autotune(e->mag, kFS, det->melT, kFS, e->db.xm, 128, b->NF, 128, kFS, st);
         if (f32_shape(b->NF, kFS, 128, 128)) gemm_autotune(e->db.xm, 128, det->melB, 128, e->gmag, kFS, b->NF, kFS, 128, st);
@@ -1444,6 +1524,33 @@ extern "C" int aware_gemm_clip_last(const float* A, int lda, const void* Bpk, co
     const int nwm = (Tp + 31) / 32;
     if (!gemm_clip_x3_supported(nwm, N, K, lda)) return AWARE_E_BADARG;
     launch_gemm_clip_x3(A, lda, Bpk, bias, C, ldc, B, nwm, Tp, N, K, 1, rstd_out, nullptr, (hipStream_t)stream, lastpk, zpart, CL);
+    LAUNCHCHK();
+    return AWARE_OK;
+}
+
+// the same block(s) on the f16 two-term kernel (gemm_h2.hip), test / roofline entry: packs Bt (device, [N][K]) and computes
+// the per-clip maxima of A into `workspace` first.  epi 0..2 as aware_gemm_clip; lastpk / zpart / CL (epi 1 only, may be
+// null / 0) as aware_gemm_clip_last.
+extern "C" size_t aware_gemm_clip_h2_workspace_bytes(int B, int N, int K) {
+    return (B > 0 && N > 0 && K > 0) ? h2_packed_bytes(N, K) + (size_t)B * 64 * sizeof(float) * 2 + 1024 : 0;
+}
+extern "C" int aware_gemm_clip_h2(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc, int B,
+                                  int Tp, int N, int K, int epi, float* rstd_io, const float* act, const void* lastpk, float* zpart,
+                                  int CL, float* amax_out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!A || !Bt || !C || !workspace || B < 1 || Tp < 1 || Tp > 128 || epi < 0 || epi > 2 || (ldb & 3)) return AWARE_E_BADARG;
+    if (epi != 0 && !rstd_io) return AWARE_E_BADARG;
+    if (epi == 2 && !act) return AWARE_E_BADARG;
+    const int nwm = (Tp + 31) / 32;
+    if (!gemm_clip_h2_supported(nwm, N, K, lda) || N % 16) return AWARE_E_BADARG;
+    if (workspace_bytes < aware_gemm_clip_h2_workspace_bytes(B, N, K)) return AWARE_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    Carver c(workspace, workspace_bytes);
+    void* pk = c.take<char>(h2_packed_bytes(N, K));
+    float* amax = c.take<float>((size_t)B * 64);
+    launch_h2_pack(Bt, ldb, N, K, pk, st);
+    launch_clip_amax(A, lda, K, 32 * nwm, B, amax, st);
+    launch_gemm_clip_h2(A, lda, pk, amax, amax_out, bias, C, ldc, B, nwm, Tp, N, K, epi, rstd_io, act, st,
+                        (epi == 1 && lastpk && zpart) ? lastpk : nullptr, zpart, CL);
     LAUNCHCHK();
     return AWARE_OK;
 }

@@ -1,0 +1,495 @@
+// Clip-aligned detector GEMM on the f16 matrix pipe with f32-level arithmetic: two-term operand split, three products.
+//
+// gfx950 has no fast path for f32 operands (v_mfma_f32_32x32x2_f32 runs at 1/16 of the 16-bit MFMA rate).  gemm_x3.hip
+// writes an f32 value as three bf16 terms and runs six partial products.  This file uses the other 16-bit format:
+//     a * 2^s = h + l + e,   h = RN_f16(a 2^s),  l = RN_f16(a 2^s - h),  |e| <= 2^-24 |a 2^s|
+// (binary16 has 11 significand bits: h is within 2^-12 relative, the residual a 2^s - h is exact in f32 and l rounds it to
+// within 2^-12 of itself).  The representation error e is at most HALF AN ULP of the f32 value: every operand looks as if it
+// had been rounded to f32 once more.  The product a*b is then h_a h_b + h_a l_b + l_a h_b (+ l_a l_b <= 2^-24 |ab|, dropped):
+// THREE v_mfma_f32_16x16x32_f16 with f32 accumulation per k-step, half the matrix-pipe time of the six-product kernel, 2/3 of
+// its LDS fragment traffic and weight bytes.  Each partial product is exact in f32 (22 significand bits).
+//
+// binary16's exponent range (normal down to 2^-14) makes the scale 2^s part of the format:
+//   * weights: one power of two per output channel (row of Wt), chosen when the weights are packed so that the row's
+//     largest magnitude lands in [2^13, 2^14); the inverse goes into the epilogue (exact).  A weight more than 2^15 below
+//     its row maximum has a subnormal l: its absolute error is then <= 2^-39 of the row maximum -- far below the f32
+//     rounding of the row's large entries, which is what bounds a dot product's error;
+//   * activations / gradients: one power of two per CLIP, from the clip's max |x|, which every producing kernel leaves as
+//     per-wave partial maxima (K/16 floats per clip: no atomics, nothing to reset) and the consumer reduces at start-up.
+// Measured against fp64 beside the f32-input MFMA kernel in tests/test_gpu_kernels.py::test_gemm_clip_x3 (mode 2) on operands
+// spanning 2^10 per row: at or below the f32 chain's error on every shape and epilogue.
+//
+// Tiling, staging, epilogues: as gemm_x3.hip (one 512-thread workgroup = all rows of one clip x 128 columns, a wave = all
+// rows x 16 columns, A split on the fly into LDS in fragment order, B fragments straight from L2, InstanceNorm statistics
+// in registers).  Reference semantics of the epilogues: detection/modules/conv1d.py:38-42.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kernels.h"
+#include "common.hpp"
+#include "split_bf16.hpp"
+
+namespace aware {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// ---------------------------------------------------------------------------------------------------
+// packing (device): Wt [N][K] f32 row-major (row pitch ldw) -> [N/16][KS][plane 0..1][lane 0..63][8 f16] + inverse scales
+// ---------------------------------------------------------------------------------------------------
+static inline size_t h2_plane_bytes(int N, int K) { return (size_t)N * (size_t)(((K + 31) / 32) * 32) * 2 * sizeof(uint16_t); }
+size_t h2_packed_bytes(int N, int K) { return h2_plane_bytes(N, K) + (size_t)N * sizeof(float); }
+const float* h2_inv_scale(const void* packed, int N, int K) { return (const float*)((const char*)packed + h2_plane_bytes(N, K)); }
+
+// power-of-two scale that brings a maximum magnitude `amax` into [2^13, 2^14); 1 for zero / tiny maxima
+__device__ __forceinline__ float h2_scale_for(float amax) {
+    const int e = (int)((__float_as_uint(amax) >> 23) & 0xFFu);
+    return e < 20 ? 1.0f : __uint_as_float((unsigned)(267 - e) << 23);
+}
+__device__ __forceinline__ float h2_pow2_inverse(float s) {            // s is a power of two
+    const unsigned e = (__float_as_uint(s) >> 23) & 0xFFu;
+    return __uint_as_float((254u - e) << 23);
+}
+
+__global__ __launch_bounds__(64) void h2_row_scale_kernel(const float* __restrict__ Wt, int ldw, int K, float* __restrict__ binv) {
+    const int n = blockIdx.x, lane = threadIdx.x;
+    float m = 0.f;
+    for (int k = lane; k < K; k += 64) m = fmaxf(m, fabsf(Wt[(size_t)n * ldw + k]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) binv[n] = h2_pow2_inverse(h2_scale_for(m));
+}
+
+__global__ __launch_bounds__(64) void h2_pack_kernel(const float* __restrict__ Wt, int ldw, int N, int K, int KS,
+                                                      const float* __restrict__ binv, u32x4* __restrict__ out) {
+    const int ks = blockIdx.x, nt = blockIdx.y, lane = threadIdx.x;
+    const int n = nt * 16 + (lane & 15), k0 = ks * 32 + 8 * (lane >> 4);
+    const float s = h2_pow2_inverse(binv[n]);
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = k0 + 2 * j;
+        const float x = k < K ? Wt[(size_t)n * ldw + k] * s : 0.f, y = k + 1 < K ? Wt[(size_t)n * ldw + k + 1] * s : 0.f;
+        const f16x2 hh = {(_Float16)x, (_Float16)y};
+        const f16x2 ll = {(_Float16)(x - (float)hh.x), (_Float16)(y - (float)hh.y)};
+        h[j] = __builtin_bit_cast(unsigned, hh);
+        l[j] = __builtin_bit_cast(unsigned, ll);
+    }
+    u32x4* o = out + ((size_t)(nt * KS + ks) * 2) * 64 + lane;
+    o[0] = u32x4{h[0], h[1], h[2], h[3]};
+    o[64] = u32x4{l[0], l[1], l[2], l[3]};
+}
+
+// Wt_dev: device [N][K] f32 (row pitch ldw), N % 16 == 0; out: device, h2_packed_bytes(N, K)
+void launch_h2_pack(const float* Wt_dev, int ldw, int N, int K, void* out, hipStream_t st) {
+    const int KS = (K + 31) / 32;
+    float* binv = (float*)((char*)out + h2_plane_bytes(N, K));
+    hipLaunchKernelGGL(h2_row_scale_kernel, dim3(N), dim3(64), 0, st, Wt_dev, ldw, K, binv);
+    hipLaunchKernelGGL(h2_pack_kernel, dim3(KS, N / 16), dim3(64), 0, st, Wt_dev, ldw, N, K, KS, binv, (u32x4*)out);
+}
+
+// per-clip max |x| of a [clips * rows_per_clip][K] matrix into the partial layout the GEMM reads: entry 0 = the maximum,
+// entries 1 .. K/16 - 1 = 0.  For operands whose producer does not leave the partials (tests, the small-batch mel kernels).
+__global__ __launch_bounds__(256) void clip_amax_kernel(const float* __restrict__ A, int lda, int K, int rows_per_clip,
+                                                         float* __restrict__ amax) {
+    __shared__ float red[4];
+    const int clip = blockIdx.x, tid = threadIdx.x;
+    const int k4 = K >> 2;
+    float m = 0.f;
+    for (int i = tid; i < rows_per_clip * k4; i += 256) {
+        const int r = i / k4, c = i % k4;
+        const float4 v = *reinterpret_cast<const float4*>(A + (size_t)(clip * rows_per_clip + r) * lda + 4 * c);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    const int np = K >> 4;
+    if (tid < np) amax[(size_t)clip * 64 + tid] = tid == 0 ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) : 0.f;
+}
+void launch_clip_amax(const float* A, int lda, int K, int rows_per_clip, int B, float* amax, hipStream_t st) {
+    hipLaunchKernelGGL(clip_amax_kernel, dim3(B), dim3(256), 0, st, A, lda, K, rows_per_clip, amax);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// the K loop of one tile (8 waves, a wave = all 32 RG rows x 16 columns)
+// ---------------------------------------------------------------------------------------------------
+// (x, y) scaled by s -> packed f16 pairs of the two planes (v_pk_mul_f32, v_cvt_pk_f16_f32, 2 v_cvt_f32_f16, v_pk_fma_f32,
+// v_cvt_pk_f16_f32: the residual is one exact fused multiply-subtract)
+__device__ __forceinline__ void h2_split_pair(float x, float y, float s, unsigned& h, unsigned& l) {
+    const float tx = x * s, ty = y * s;
+    const f16x2 hh = {(_Float16)tx, (_Float16)ty};
+    const f16x2 ll = {(_Float16)(tx - (float)hh.x), (_Float16)(ty - (float)hh.y)};
+    h = __builtin_bit_cast(unsigned, hh);
+    l = __builtin_bit_cast(unsigned, ll);
+}
+
+// acc[m] += (A[bm + 16 m .. +16)[0..K) * 2^sa) * (B 2^sb)^T for the wave's 16 columns bn + 16 wave ..; the caller unscales.
+// `lds`: 2 * 2 * 2 * 2RG KiB of staging memory (two K tiles of 64, two K32 steps, two planes); every wave of the workgroup
+// calls this with the same arguments; the caller provides a barrier between two calls that reuse `lds`.
+template <int RG>
+__device__ __forceinline__ void h2_tile_gemm(const float* __restrict__ A, int lda, const u32x4* __restrict__ Bpk, int K, int bm,
+                                             int bn, unsigned char* lds, f32x4 (&acc)[2 * RG], int row_limit, float ascale) {
+    constexpr int NT = 512;
+    constexpr int MT = 2 * RG;            // 16-row tiles per clip
+    constexpr int MH = RG;                // ... per half (the unit of the A-fragment schedule)
+    constexpr int FRAG = 1024;            // one 16-row x 32-k f16 fragment image, bytes
+    constexpr int PLANE = MT * FRAG;
+    constexpr int KSS = 2 * PLANE;        // one K32 step
+    constexpr int BUF = 2 * KSS;          // one K tile (BK = 64)
+    constexpr int NCH = (RG * 256 + NT - 1) / NT;     // 8-float chunks of the A tile per thread
+
+    bm = __builtin_amdgcn_readfirstlane(bm);
+    bn = __builtin_amdgcn_readfirstlane(bn);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int srow = tid >> 3, sc = tid & 7;          // chunk i of this thread: row srow + 64 i, k = 8 sc
+    unsigned rb[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) rb[t] = (unsigned)(t * KSS + kg * 256 + ((r16 ^ (4 * t + kg)) * 16));
+
+    const int KS2 = K >> 5;
+    const int nkt = K >> 6;
+    const u32x4* bp = Bpk + ((size_t)((bn >> 4) + wave) * KS2) * 128;                // uniform; + lane per thread
+    const float* ap = A + (size_t)bm * lda;                                          // uniform
+    unsigned roff[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) roff[i] = (unsigned)(min(srow + (NT / 8) * i, row_limit - 1) * lda + sc * 8);
+
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    float4 ra[NCH][2];
+    auto chunk_ok = [&](int i) { return (RG * 256) % NT == 0 || tid + NT * i < RG * 256; };
+    auto gload_c = [&](int i, int kt) {
+        if (chunk_ok(i)) {
+            const float* p = ap + kt * 64;
+            ra[i][0] = *reinterpret_cast<const float4*>(p + roff[i]);
+            ra[i][1] = *reinterpret_cast<const float4*>(p + roff[i] + 4);
+        }
+    };
+    auto split_store_c = [&](int i, unsigned boff) {
+        if (chunk_ok(i)) {
+            const int row = srow + (NT / 8) * i;
+            uint4 qh, ql;
+            h2_split_pair(ra[i][0].x, ra[i][0].y, ascale, qh.x, ql.x);
+            h2_split_pair(ra[i][0].z, ra[i][0].w, ascale, qh.y, ql.y);
+            h2_split_pair(ra[i][1].x, ra[i][1].y, ascale, qh.z, ql.z);
+            h2_split_pair(ra[i][1].z, ra[i][1].w, ascale, qh.w, ql.w);
+            unsigned char* d = lds + boff + (sc >> 2) * KSS + (row >> 4) * FRAG + (sc & 3) * 256 + (((row & 15) ^ sc) * 16);
+            *reinterpret_cast<uint4*>(d) = qh;
+            *reinterpret_cast<uint4*>(d + PLANE) = ql;
+        }
+    };
+    u32x4 bq[2][2];
+    auto loadB = [&](int set, int ks2) {
+        ks2 = ks2 < KS2 ? ks2 : KS2 - 1;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) bq[set][p] = (bp + ((size_t)ks2 * 2 + p) * 64)[(unsigned)lane];
+    };
+    auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    // A fragments: the h plane is double-buffered (the next quarter's h fragments are requested a whole quarter -- 3 MH MFMAs
+    // -- ahead), the l plane single-buffered and refilled right after its only product of the quarter (2 MH MFMAs ahead)
+    f16x8 ah[2][MH], al[MH];
+    auto read_h = [&](int set, unsigned off) {
+#pragma unroll
+        for (int m = 0; m < MH; ++m) ah[set][m] = *reinterpret_cast<const f16x8*>(lds + off + m * FRAG);
+    };
+    auto read_l = [&](unsigned off) {
+#pragma unroll
+        for (int m = 0; m < MH; ++m) al[m] = *reinterpret_cast<const f16x8*>(lds + off + PLANE + m * FRAG);
+    };
+#define H2_MFMA(a_, b_, hf_)                                                                                                   \
+    _Pragma("unroll") for (int m = 0; m < MH; ++m)                                                                             \
+        acc[(hf_) * MH + m] = __builtin_amdgcn_mfma_f32_16x16x32_f16((a_)[m], __builtin_bit_cast(f16x8, (b_)), acc[(hf_) * MH + m], 0, 0, 0)
+#define H2_PIN(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) gload_c(i, 0);
+    loadB(0, 0);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) split_store_c(i, 0);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) gload_c(i, nkt > 1 ? 1 : 0);
+    lds_barrier();
+    read_h(0, rb[0]);
+    read_l(rb[0]);
+    for (int kt = 0; kt < nkt; ++kt) {
+        const unsigned cur = (kt & 1) * BUF, nxt = BUF - cur;
+        const int ktn = kt + 2 < nkt ? kt + 2 : nkt - 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                 // quarter = (K32 step q>>1, row half q&1)
+            const int t = q >> 1, hf = q & 1;
+            if (hf == 0) loadB((t + 1) & 1, kt * 2 + t + 1);          // B fragments one K32 step ahead
+            if (q < NCH) {
+                split_store_c(q, nxt);
+                gload_c(q, ktn);
+            }
+            const unsigned noff = q < 3 ? cur + rb[(q + 1) >> 1] + ((q + 1) & 1) * MH * FRAG : nxt + rb[0];
+            if (q < 3) { read_h((q + 1) & 1, noff); H2_PIN(0x100, MH); }
+            H2_MFMA(al, bq[t][0], hf);                // l_a * h_b
+            H2_PIN(0x008, MH);
+            if (q == 3) {                             // tile kt+1 is complete; every wave has finished its reads of tile kt
+                lds_barrier();
+                read_h(0, noff);
+                H2_PIN(0x100, MH);
+            }
+            read_l(noff);
+            H2_PIN(0x100, MH);
+            H2_MFMA(ah[q & 1], bq[t][1], hf);         // h_a * l_b
+            H2_MFMA(ah[q & 1], bq[t][0], hf);         // h_a * h_b
+            H2_PIN(0x008, 2 * MH);
+        }
+    }
+#undef H2_PIN
+#undef H2_MFMA
+}
+
+// ---------------------------------------------------------------------------------------------------
+// the conv block / data-gradient kernel for uniform batches (epilogues as gemm_clip_x3_kernel)
+// ---------------------------------------------------------------------------------------------------
+template <int RG, int EPI>
+__global__ __launch_bounds__(512, RG <= 3 ? 4 : 2) void gemm_clip_h2_kernel(
+    const float* __restrict__ A, int lda, const u32x4* __restrict__ Bpk, const float* __restrict__ binv,
+    const float* __restrict__ amax_in, float* __restrict__ amax_out, const float* __restrict__ bias, float* __restrict__ C, int ldc,
+    int Tp, int N, int K, int tiles_n, int ntiles, float* __restrict__ rstd_io, const float* __restrict__ act,
+    const u32x4* __restrict__ Lpk, float* __restrict__ zpart, int CL) {
+    constexpr int MT = 2 * RG;
+    constexpr int MH = RG;
+    constexpr int FRAG = 1024;
+    constexpr int BUF = 2 * 2 * MT * FRAG;
+    // (the FWD_LAST epilogue re-lays the output tile as f32 [32 RG][132] in the same memory, then parks 8 waves x MH x 3
+    //  partial tiles of 1 KiB there)
+    constexpr int LASTB = 32 * RG * 132 * 4 > 8 * MH * 3 * FRAG ? 32 * RG * 132 * 4 : 8 * MH * 3 * FRAG;
+    constexpr int LDSB = (EPI == X3_FWD_LAST && LASTB > 2 * BUF) ? LASTB : 2 * BUF;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDSB];
+
+    // block -> (clip, column slab): blocks b and b + 8 share an XCD (observed round-robin placement; speed only).  An XCD takes
+    // a contiguous range of clips and walks it slab-group-major, `sg` slabs at a time whose packed weights (sg * 128 * K * 4
+    // bytes) fit its L2 beside the activation rows in flight (gemm_x3.hip has the measurements).
+    int id = blockIdx.x;
+    int clip, slab_;
+    if ((ntiles & 7) == 0) {
+        const int x = id & 7, j = id >> 3, R = ntiles >> 3;
+        const int nclip = R / tiles_n;
+        if (nclip * tiles_n == R && nclip > 0) {
+            int sg = (int)(3355443u / (unsigned)(128 * K * 4));
+            sg = sg < 1 ? 1 : (sg > tiles_n ? tiles_n : sg);
+            while (tiles_n % sg) --sg;
+            const int per_group = nclip * sg;
+            const int grp = j / per_group, r = j % per_group;
+            clip = x * nclip + r / sg;
+            slab_ = grp * sg + r % sg;
+        } else {
+            id = x * R + j;
+            clip = id / tiles_n;
+            slab_ = id % tiles_n;
+        }
+    } else {
+        clip = id / tiles_n;
+        slab_ = id % tiles_n;
+    }
+    const int bm = clip * 32 * RG;
+    const int bn = slab_ * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kg = lane >> 4;
+
+    // the clip's scale from the producer's partial maxima (K/16 of them: one per wave of each of its workgroups)
+    float am = lane < (K >> 4) ? amax_in[(size_t)clip * 64 + lane] : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
+    const float ascale = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(h2_scale_for(am))));
+
+    f32x4 acc[MT];
+    h2_tile_gemm<RG>(A, lda, Bpk, K, bm, bn, lds, acc, 32 * RG, ascale);
+
+    // ---- epilogue: lane holds rows m*16 + 4*kg + e (e = 0..3) of column col ----
+    const int col = bn + wave * 16 + r16;
+    const float unscale = h2_pow2_inverse(ascale) * binv[col];
+    const float invT = 1.0f / (float)Tp;
+    float omax = 0.f;                                   // max |output| of this wave's tile, for the next GEMM's scale
+    if (EPI == X3_PLAIN) {
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = m * 16 + 4 * kg + e;
+                const float o = row < Tp ? acc[m][e] * unscale + bv : 0.f;
+                omax = fmaxf(omax, fabsf(o));
+                C[(size_t)(bm + row) * ldc + col] = o;
+            }
+    } else if (EPI == X3_FWD || EPI == X3_FWD_LAST) {
+        const float bv = bias ? bias[col] : 0.f;
+        float s = 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = m * 16 + 4 * kg + e;
+                acc[m][e] = acc[m][e] * unscale + bv;
+                if (row < Tp) s += acc[m][e];
+            }
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        const float mean = s * invT;
+        float qq = 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = m * 16 + 4 * kg + e;
+                if (row < Tp) { const float d = acc[m][e] - mean; qq += d * d; }
+            }
+        qq += __shfl_xor(qq, 16);
+        qq += __shfl_xor(qq, 32);
+        const float rs = 1.0f / sqrtf(qq * invT + 1e-5f);      // biased variance, eps 1e-5 (InstanceNorm1d defaults)
+        if (kg == 0) rstd_io[(size_t)clip * N + col] = rs;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = m * 16 + 4 * kg + e;
+                const float u = (acc[m][e] - mean) * rs;
+                const float o = row < Tp ? (u > 0.f ? u : 0.2f * u) : 0.f;
+                acc[m][e] = o;
+                omax = fmaxf(omax, fabsf(o));
+                C[(size_t)(bm + row) * ldc + col] = o;
+            }
+    } else {
+        // X3_BWD: acc = dL/dA of the previous block's output (read from `act`, post-activation);
+        //         C = dL/dZ = rstd * (dU - mean_t dU - u * mean_t(dU*u)),  dU = acc * lrelu'(u)
+        const float rs = rstd_io[(size_t)clip * N + col];
+        float s1 = 0.f, s2 = 0.f;
+        float u[MT][4];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = m * 16 + 4 * kg + e;
+                // unconditional load (padding rows exist and hold zeros): a branch here would serialise the loads
+                const float av = act[(size_t)(bm + row) * ldc + col];
+                const bool valid = row < Tp;
+                const float uv = valid ? (av > 0.f ? av : av * 5.0f) : 0.f;                 // invert LeakyReLU(0.2)
+                const float du = valid ? acc[m][e] * unscale * (av > 0.f ? 1.f : 0.2f) : 0.f;
+                acc[m][e] = du;
+                u[m][e] = uv;
+                s1 += du;
+                s2 += du * uv;
+            }
+        s1 += __shfl_xor(s1, 16);
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 16);
+        s2 += __shfl_xor(s2, 32);
+        const float m1 = s1 * invT, m2 = s2 * invT;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = m * 16 + 4 * kg + e;
+                const float o = row < Tp ? rs * (acc[m][e] - m1 - u[m][e] * m2) : 0.f;
+                omax = fmaxf(omax, fabsf(o));
+                C[(size_t)(bm + row) * ldc + col] = o;
+            }
+    }
+    if (amax_out) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o));
+        if (lane == 0) amax_out[(size_t)clip * 64 + slab_ * 8 + wave] = omax;
+    }
+    if (EPI == X3_FWD_LAST) {
+        // acc[m][e] holds this block's output (zero in padding rows).  The next conv block is the skinny last one (CL <= 48
+        // channels): its K = this N is split over the column slabs, so this workgroup contributes the partial
+        // z_part[slab] = out[:, slab] * Wlast[:, slab]^T, computed on the bf16 pipe with the exact three-way split (operands
+        // of gemm_x3.hip's pack: the tile is re-laid as A fragments (k = column) through LDS).  Wave w takes K32 step w>>1 of
+        // the slab's 128 columns and half w&1 of the row tiles; the four t-partials are then summed through LDS.
+        const int slab = bn >> 7, KS2L = N >> 5, ncl = (CL + 15) >> 4;
+        const int tq = wave >> 1, mh = wave & 1;
+        bf16x8 bl[3][3];
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+            if (n < ncl) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    bl[n][p] = __builtin_bit_cast(bf16x8, Lpk[(((size_t)n * KS2L + 4 * slab + tq) * 3 + p) * 64 + lane]);
+            }
+        __syncthreads();                                  // every wave is done with the staging buffers
+        float* const T = reinterpret_cast<float*>(lds);
+        constexpr int TP = 132;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) T[(16 * m + 4 * kg + e) * TP + 16 * wave + r16] = acc[m][e];
+        __syncthreads();
+        f32x4 zt[MH][3];
+#pragma unroll
+        for (int mm = 0; mm < MH; ++mm) {
+#pragma unroll
+            for (int n = 0; n < 3; ++n) zt[mm][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* src = T + (16 * (mh * MH + mm) + r16) * TP + 32 * tq + 8 * kg;
+            const float4 x0 = *reinterpret_cast<const float4*>(src), x1 = *reinterpret_cast<const float4*>(src + 4);
+            uint4 q0, q1, q2;
+            split_pair(x0.x, x0.y, q0.x, q1.x, q2.x);
+            split_pair(x0.z, x0.w, q0.y, q1.y, q2.y);
+            split_pair(x1.x, x1.y, q0.z, q1.z, q2.z);
+            split_pair(x1.z, x1.w, q0.w, q1.w, q2.w);
+            bf16x8 a[3];
+            a[0] = __builtin_bit_cast(bf16x8, q0); a[1] = __builtin_bit_cast(bf16x8, q1); a[2] = __builtin_bit_cast(bf16x8, q2);
+#pragma unroll
+            for (int term = 0; term < 6; ++term) {
+                const int pa = term == 0 ? 2 : (term == 1 || term == 3) ? 1 : 0;
+                const int pb = term == 2 ? 2 : (term == 1 || term == 4) ? 1 : 0;
+#pragma unroll
+                for (int n = 0; n < 3; ++n)
+                    if (n < ncl) zt[mm][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[pa], bl[n][pb], zt[mm][n], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                  // all fragment reads done: the buffer becomes the partial store
+#pragma unroll
+        for (int mm = 0; mm < MH; ++mm)
+#pragma unroll
+            for (int n = 0; n < 3; ++n)
+                *reinterpret_cast<f32x4*>(lds + (size_t)((wave * MH + mm) * 3 + n) * FRAG + lane * 16) = zt[mm][n];
+        __syncthreads();
+        if (wave < MT) {
+            const int smh = wave / MH, smm = wave % MH;   // this wave finishes row tile `wave`
+            float* zp = zpart + (size_t)slab * ((size_t)(ntiles / tiles_n) * 32 * RG * CL) + (size_t)(bm + 16 * wave + 4 * kg) * CL;
+#pragma unroll
+            for (int n = 0; n < 3; ++n)
+                if (n < ncl) {
+                    f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        t += *reinterpret_cast<const f32x4*>(lds + (size_t)(((2 * q + smh) * MH + smm) * 3 + n) * FRAG + lane * 16);
+                    if (16 * n + r16 < CL) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) zp[(size_t)e * CL + 16 * n + r16] = t[e];
+                    }
+                }
+        }
+    }
+}
+
+bool gemm_clip_h2_supported(int nwm, int N, int K, int lda) {
+    return nwm >= 1 && nwm <= 4 && N % 128 == 0 && K % 64 == 0 && K <= 1024 && lda % 4 == 0;
+}
+
+// Bpk: launch_h2_pack image of Wt [N][K]; amax_in: [B][64] partial maxima of A's clips (K/16 valid per clip); amax_out: the
+// same for C ([B][64], N/16 written per clip) or null; lastpk / zpart / CL as launch_gemm_clip_x3 (gemm_x3.hip's pack)
+void launch_gemm_clip_h2(const float* A, int lda, const void* Bpk, const float* amax_in, float* amax_out, const float* bias,
+                         float* C, int ldc, int B, int nwm, int Tp, int N, int K, int epi, float* rstd_io, const float* act,
+                         hipStream_t st, const void* lastpk, float* zpart, int CL) {
+    const int tn = N / 128;
+    const float* binv = h2_inv_scale(Bpk, N, K);
+    if (epi == X3_FWD && lastpk && zpart) epi = X3_FWD_LAST;
+#define HK(M_, E_) hipLaunchKernelGGL((gemm_clip_h2_kernel<M_, E_>), dim3(tn * B), dim3(512), 0, st, A, lda, (const u32x4*)Bpk,     \
+                                      binv, amax_in, amax_out, bias, C, ldc, Tp, N, K, tn, tn * B, rstd_io, act,                   \
+                                      (const u32x4*)lastpk, zpart, CL)
+#define HM(E_) switch (nwm) { case 1: HK(1, E_); break; case 2: HK(2, E_); break; case 3: HK(3, E_); break; default: HK(4, E_); break; }
+    if (epi == X3_FWD) { HM(X3_FWD) } else if (epi == X3_BWD) { HM(X3_BWD) } else if (epi == X3_FWD_LAST) { HM(X3_FWD_LAST) }
+    else { HM(X3_PLAIN) }
+#undef HM
+#undef HK
+}
+
+}  // namespace aware

@@ -29,11 +29,9 @@
 #include <string.h>
 #include "kernels.h"
 #include "common.hpp"
+#include "split_bf16.hpp"
 
 namespace aware {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------------------------------
 // host side: three-way bf16 split (round to nearest even on the f32 bits) and fragment-order packing
@@ -53,27 +51,6 @@ static inline float bf16_to_f32(uint16_t b) {
 
 // either operand order (x3_pack: k16 steps of 32-column tiles; x3_pack: k32 steps of 16-column tiles), K rounded up to 32
 size_t x3_packed_bytes(int N, int K) { return (size_t)N * (size_t)(((K + 31) / 32) * 32) * 3 * sizeof(uint16_t); }
-
-// ---------------------------------------------------------------------------------------------------
-// device side
-// ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
-}
-// (x, y) -> packed bf16 pairs of the three planes; residuals are exact f32 subtractions
-__device__ __forceinline__ void split_pair(float x, float y, unsigned& p0, unsigned& p1, unsigned& p2) {
-    p0 = cvt_pk_bf16(x, y);
-    const float rx = x - __uint_as_float(p0 << 16), ry = y - __uint_as_float(p0 & 0xFFFF0000u);
-    p1 = cvt_pk_bf16(rx, ry);
-    const float sx = rx - __uint_as_float(p1 << 16), sy = ry - __uint_as_float(p1 & 0xFFFF0000u);
-    p2 = cvt_pk_bf16(sx, sy);
-}
-
-enum { X3_PLAIN = 0, X3_FWD = 1, X3_BWD = 2, X3_FWD_LAST = 3 };   // 3: FWD + split-K partials of the next (last, skinny) conv
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Wt: [N][K] row-major f32 (the NT operand: C = A * Wt^T), N % 16 == 0; out: x3_packed_bytes(N, K)
 
@@ -935,7 +912,8 @@ template <int RG>
 __global__ __launch_bounds__(512, 2) void mel_front_x3_kernel(const float* __restrict__ mag, int lda, const u32x4* __restrict__ Bpk,
                                                                const int* __restrict__ frame_off, const int* __restrict__ pool_off,
                                                                float* __restrict__ xm, float* __restrict__ x0,
-                                                               float* __restrict__ stats, float* __restrict__ gstat, int K) {
+                                                               float* __restrict__ stats, float* __restrict__ gstat, int K,
+                                                               float* __restrict__ amax_out) {
     constexpr int MT = 2 * RG;
     constexpr int FRAG = 1024;
     constexpr int BUF = 2 * 3 * MT * FRAG;
@@ -994,14 +972,22 @@ __global__ __launch_bounds__(512, 2) void mel_front_x3_kernel(const float* __res
     }
     __syncthreads();                                                   // the tile has been read: the buffer takes the pooled tile
     // pooled rows: the frame pair (2 tp, 2 tp + 1) is the register pair (e, e + 1) of one lane
+    float pmax = 0.f;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int tp = (m * 16 + 4 * kg) / 2 + h;
             const float u0 = (acc[m][0][2 * h] - mu) * rs, u1 = (acc[m][0][2 * h + 1] - mu) * rs;
-            Tm[tp][c] = tp < Tp ? 0.5f * (u0 * ginv + u1 * ginv) : 0.f;                 // AvgPool1d(2, 2)
+            const float pv = tp < Tp ? 0.5f * (u0 * ginv + u1 * ginv) : 0.f;           // AvgPool1d(2, 2)
+            Tm[tp][c] = pv;
+            pmax = fmaxf(pmax, fabsf(pv));
         }
+    if (amax_out) {                                                    // partial maxima of the pooled tile (gemm_h2.hip's scale)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) pmax = fmaxf(pmax, __shfl_xor(pmax, o));
+        if (lane == 0) amax_out[(size_t)b * 64 + wave] = pmax;
+    }
     __syncthreads();
     const int Tpad = (Tp + 31) & ~31;
     float* o = x0 + (size_t)pool_off[b] * 128;
@@ -1012,9 +998,9 @@ __global__ __launch_bounds__(512, 2) void mel_front_x3_kernel(const float* __res
 
 bool mel_front_x3_supported(int T, int K, int lda) { return T >= 2 && T <= 192 && K % 64 == 0 && lda % 4 == 0; }
 void launch_mel_front_x3(const float* mag, int lda, const void* melTpk, const int* frame_off, const int* pool_off, float* xm,
-                         float* x0, float* stats, float* gstat, int B, int T, int K, hipStream_t st) {
+                         float* x0, float* stats, float* gstat, int B, int T, int K, hipStream_t st, float* amax_out) {
 #define MF(R_) hipLaunchKernelGGL((mel_front_x3_kernel<R_>), dim3(B), dim3(512), 0, st, mag, lda, (const u32x4*)melTpk, frame_off,  \
-                                  pool_off, xm, x0, stats, gstat, K)
+                                  pool_off, xm, x0, stats, gstat, K, amax_out)
     const int rg = (T + 31) / 32;
     switch (rg) { case 1: MF(1); break; case 2: MF(2); break; case 3: MF(3); break; case 4: MF(4); break; case 5: MF(5); break;
                   default: MF(6); break; }
@@ -1331,7 +1317,8 @@ __global__ __launch_bounds__(512, RG <= 3 ? 4 : 2) void readout_grad_x3_kernel(c
                                                                                 const unsigned char* __restrict__ img_in,
                                                                                 const u32x4* __restrict__ WTpk,
                                                                                 const float* __restrict__ rstd_prev,
-                                                                                float* __restrict__ dZ, int Tp, int G, int ntiles) {
+                                                                                float* __restrict__ dZ, int Tp, int G, int ntiles,
+                                                                                float* __restrict__ amax_out) {
     constexpr int MT = 2 * RG;
     constexpr int FRAG = 1024;
     constexpr int KSC = 2;
@@ -1439,6 +1426,7 @@ __global__ __launch_bounds__(512, RG <= 3 ? 4 : 2) void readout_grad_x3_kernel(c
     }
     m1.x *= invT; m1.y *= invT; m1.z *= invT; m1.w *= invT;
     m2.x *= invT; m2.y *= invT; m2.z *= invT; m2.w *= invT;
+    float omax = 0.f;
 #pragma unroll
     for (int j2 = 0; j2 < MT; ++j2) {
         const int row = rr + 16 * j2;
@@ -1449,7 +1437,13 @@ __global__ __launch_bounds__(512, RG <= 3 ? 4 : 2) void readout_grad_x3_kernel(c
             o.z = rsp.z * (du[j2].z - m1.z - hv[j2].z * m2.z);
             o.w = rsp.w * (du[j2].w - m1.w - hv[j2].w * m2.w);
         }
+        omax = fmaxf(fmaxf(omax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         *reinterpret_cast<float4*>(dZ + (size_t)(bm + row) * ci + gcol) = o;
+    }
+    if (amax_out) {                                     // partial maxima of the gradient tile (gemm_h2.hip's scale)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o));
+        if (lane == 0) amax_out[(size_t)clip * 64 + g * 8 + wave] = omax;
     }
 }
 
@@ -1618,7 +1612,7 @@ size_t readout_x3_image_bytes(int B, int nwm) { return (size_t)B * 2 * 3 * (2 * 
 void launch_readout_x3(const float* hin, int ci, const float* zpart, int nslab, const float* bias, const void* WTpk,
                        const float* rstd_prev, const float* target, float* pred, float* loss, float* best_loss, int* improved,
                        int* step, float* dZ, int B, int nwm, int Tp, int C, int nbits, int loss_kind, hipStream_t st,
-                       const float* loss_add, void* img) {
+                       const float* loss_add, void* img, float* amax_out) {
     const int G = ci / 128, nc = (C + 15) / 16;
     const size_t slab_stride = (size_t)B * 32 * nwm * C;
 #define RH(M_, N_) hipLaunchKernelGGL((readout_head_x3_kernel<M_, N_>), dim3(B), dim3(512), 0, st, zpart, nslab, slab_stride, bias,    \
@@ -1629,7 +1623,7 @@ void launch_readout_x3(const float* hin, int ci, const float* zpart, int nslab, 
 #undef RN
 #undef RH
 #define RGK(M_) hipLaunchKernelGGL((readout_grad_x3_kernel<M_>), dim3(B * G), dim3(512), 0, st, hin, ci, (const unsigned char*)img, \
-                                   (const u32x4*)WTpk, rstd_prev, dZ, Tp, G, B * G)
+                                   (const u32x4*)WTpk, rstd_prev, dZ, Tp, G, B * G, amax_out)
     switch (nwm) { case 1: RGK(1); break; case 2: RGK(2); break; case 3: RGK(3); break; default: RGK(4); break; }
 #undef RGK
 }

@@ -115,7 +115,8 @@ bool gemm_clip_x3_supported(int nwm, int N, int K, int lda);
 // launch_mel_norm_fwd leaves them
 bool mel_front_x3_supported(int T, int K, int lda);
 void launch_mel_front_x3(const float* mag, int lda, const void* melTpk, const int* frame_off, const int* pool_off, float* xm,
-                         float* x0, float* stats, float* gstat, int B, int T, int K, hipStream_t st);
+                         float* x0, float* stats, float* gstat, int B, int T, int K, hipStream_t st, float* amax_out = nullptr);
+// (amax_out: [B][64], 8 partial maxima of |x0| per clip for gemm_h2.hip, or null)
 // backward of the same block for the same batches: data gradient of the first conv block (dZ [NP][K], wTpk = x3_pack of its
 // transposed weights [128][K]) + AvgPool / GlobalStandardize / InstanceNorm backward; xm: raw mel in, dL/d(mel) out
 void launch_mel_back_x3(const float* dZ, int lda, const void* wTpk, const int* frame_off, const int* pool_off, float* xm,
@@ -125,6 +126,15 @@ void launch_mel_back_x3(const float* dZ, int lda, const void* wTpk, const int* f
 void launch_gemm_clip_x3(const float* A, int lda, const void* Bpk, const float* bias, float* C, int ldc, int B, int nwm,
                          int Tp, int N, int K, int epi, float* rstd_io, const float* act, hipStream_t st,
                          const void* lastpk = nullptr, float* zpart = nullptr, int CL = 0, int Mrows = 0);
+// ---- gemm_h2.hip: the same block on the f16 matrix pipe, two-term operand split, three products (f32-level) ----
+size_t h2_packed_bytes(int N, int K);
+void launch_h2_pack(const float* Wt_dev, int ldw, int N, int K, void* out, hipStream_t st);   // device -> device
+void launch_clip_amax(const float* A, int lda, int K, int rows_per_clip, int B, float* amax, hipStream_t st);
+bool gemm_clip_h2_supported(int nwm, int N, int K, int lda);
+// amax_in: [B][64] partial maxima of |A| per clip (K/16 valid); amax_out: [B][64] the same of C (N/16 written) or null
+void launch_gemm_clip_h2(const float* A, int lda, const void* Bpk, const float* amax_in, float* amax_out, const float* bias,
+                         float* C, int ldc, int B, int nwm, int Tp, int N, int K, int epi, float* rstd_io, const float* act,
+                         hipStream_t st, const void* lastpk = nullptr, float* zpart = nullptr, int CL = 0);
 // (Mrows > 0, plain epilogue only: the matrices have Mrows < B*32*nwm rows -- the last row block is partial)
 // the same block for ragged batches / clips of any length (one launch; clips longer than 96 pooled frames in two passes)
 void launch_gemm_ragged_x3(const float* A, int lda, const void* Bpk, const float* bias, float* C, int ldc, int B,
@@ -137,7 +147,8 @@ bool readout_x3_supported(int nwm, int ci, int C);
 void launch_readout_x3(const float* hin, int ci, const float* zpart, int nslab, const float* bias, const void* WTpk,
                        const float* rstd_prev, const float* target, float* pred, float* loss, float* best_loss, int* improved,
                        int* step, float* dZ, int B, int nwm, int Tp, int C, int nbits, int loss_kind, hipStream_t st,
-                       const float* loss_add, void* img);
+                       const float* loss_add, void* img, float* amax_out = nullptr);
+// (amax_out: [B][64], ci/16 partial maxima of |dZ| per clip for gemm_h2.hip, or null)
 size_t readout_x3_image_bytes(int B, int nwm);      // scratch `img` of launch_readout_x3 (must not alias dZ)
 // ragged batches: data gradient of the last conv from dZl (float32 rows, pitch 64, zero K padding: launch_tail with ldz = 64)
 // with the backward of the previous block's InstanceNorm + LeakyReLU; ci % 128 == 0, last conv of at most 64 channels

@@ -16,6 +16,7 @@ from ._lib import AwareHipError, EmbedConfig, check, load_library, require_gpu
 
 SPEC_STRIDE = 256
 FULL_STRIDE = 520
+CONV_PIPES = {"f16x2": 0, "f32": 1, "bf16x3": 2}
 LOSS_KINDS = {"push_extremes": 0, "mse": 1, "hinge": 2, "sign": 3, "push_sigmoid": 4, "ber": 5, "push_extremes_l1": 6}
 
 
@@ -312,18 +313,20 @@ class EmbedSession:
 
     def __init__(self, plan: Plan, det: DetectorWeights, batch: Batch, num_iterations=400, tolerance_db=6.0,
                  loss="push_extremes", lr=0.1, beta1=0.9, beta2=0.999, eps=1e-8, momentum_decay=4e-3,
-                 use_graph=True, conv_pipe="bf16x3", fused_readout=True, dsp_path="stream", l1_weight=0.0):
-        """conv_pipe: "bf16x3" (default: bf16 matrix pipe, exact three-way operand split) or "f32" (f32-input MFMA);
+                 use_graph=True, conv_pipe="f16x2", fused_readout=True, dsp_path="stream", l1_weight=0.0):
+        """conv_pipe: "f16x2" (default: conv blocks of chip-filling uniform batches on the f16 matrix pipe, two-term operand
+        split, three products -- gemm_h2.hip; everything else as "bf16x3"), "bf16x3" (bf16 matrix pipe, exact three-way operand
+        split, six products -- gemm_x3.hip) or "f32" (f32-input MFMA);
         fused_readout=False selects the three-kernel read-out that ragged batches use; dsp_path: "stream" (default:
         streaming wave kernels) or "staged" (workgroup-staged kernels) for the STFT / iSTFT stages (aware_embed_config)."""
         self.lib = load_library()
         self.plan, self.det, self.batch = plan, det, batch
         if loss not in LOSS_KINDS:
             raise ValueError(f"Unknown loss type: {loss}. Available on the HIP path: {list(LOSS_KINDS)}")
-        if conv_pipe not in ("bf16x3", "f32"):
+        if conv_pipe not in CONV_PIPES:
             raise ValueError(f"Unknown conv_pipe: {conv_pipe}")
         self.cfg = EmbedConfig(int(num_iterations), float(tolerance_db), LOSS_KINDS[loss], lr, beta1, beta2, eps,
-                               momentum_decay, int(bool(use_graph)), 0 if conv_pipe == "bf16x3" else 1,
+                               momentum_decay, int(bool(use_graph)), CONV_PIPES[conv_pipe],
                                0 if fused_readout else 1, {"stream": 0, "staged": 1}[dsp_path], float(l1_weight))
         self.nbytes = self.lib.aware_embed_workspace_bytes(batch.h, det.h)
         self.ws = torch.empty(self.nbytes, dtype=torch.uint8, device=_dev())
@@ -435,6 +438,33 @@ def gemm_clip(a: torch.Tensor, bt: torch.Tensor, bias, B: int, Tp: int, epi: int
     check(lib.aware_gemm_clip(_ptr(a), a.stride(0), _ptr(bt), bt.stride(0), _ptr(packed), _ptr(bias), _ptr(c), N, B, Tp, N, K,
                               epi, _ptr(rstd), _ptr(act), mode, _stream()), "aware_gemm_clip")
     return c, rstd
+
+
+def gemm_clip_h2(a: torch.Tensor, bt: torch.Tensor, bias, B: int, Tp: int, epi: int = 0, rstd=None, act=None, w_last=None):
+    """One clip-aligned conv block on the f16 two-term kernel (aware_gemm_clip_h2; the embed loop's default conv pipe).
+    Returns (C, rstd, amax_out[B, 64]) and, with w_last [CL, N] (epi 1), also zpart [N/128, M, CL]."""
+    lib = load_library()
+    M, K = a.shape
+    N = bt.shape[0]
+    dev = a.device
+    btd = bt.to(dev).contiguous()
+    c = torch.empty((M, N), dtype=torch.float32, device=dev)
+    if rstd is None:
+        rstd = torch.zeros((B, N), dtype=torch.float32, device=dev)
+    amax = torch.zeros((B, 64), dtype=torch.float32, device=dev)
+    nbytes = int(lib.aware_gemm_clip_h2_workspace_bytes(B, N, K))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    pkl, zpart, CL = None, None, 0
+    if w_last is not None:
+        CL = w_last.shape[0]
+        wl = torch.zeros((16 * ((CL + 15) // 16), N), dtype=torch.float32)
+        wl[:CL] = w_last.detach().cpu().float()
+        pkl = x3_pack(wl)
+        zpart = torch.zeros((N // 128, M, CL), dtype=torch.float32, device=dev)
+    check(lib.aware_gemm_clip_h2(_ptr(a), a.stride(0), _ptr(btd), btd.stride(0), _ptr(bias), _ptr(c), N, B, Tp, N, K, epi, _ptr(rstd),
+                                 _ptr(act), _ptr(pkl), _ptr(zpart), CL, _ptr(amax), _ptr(ws), nbytes, _stream()), "aware_gemm_clip_h2")
+    torch.cuda.current_stream().synchronize()
+    return (c, rstd, amax) if w_last is None else (c, rstd, amax, zpart)
 
 
 def gemm_clip_last(a: torch.Tensor, bt: torch.Tensor, bias, w_last: torch.Tensor, B: int, Tp: int):

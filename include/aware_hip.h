@@ -192,10 +192,15 @@ typedef struct aware_embed_config {
     float lr, beta1, beta2, eps, momentum_decay;   /* 0.1, 0.9, 0.999, 1e-8, 4e-3 */
     int use_graph;           /* 1: capture one iteration into a hipGraph and replay it */
     /* kernel choices of this session (zero = default).
-     * conv_pipe 0: the detector's GEMMs run on the bf16 matrix pipe with every f32 operand split exactly into three
-     *   bf16 terms, six partial products per multiply-add, f32 accumulation (f32-equivalent accuracy;
-     *   csrc/gemm_x3.hip) wherever K % 64 == 0 and N % 128 == 0, f32 MFMA otherwise.
-     * conv_pipe 1: f32-input MFMA everywhere (the pipe the bf16 kernel is tested against).
+     * conv_pipe 0: the conv blocks and their data-gradient GEMMs of a uniform batch that fills the chip run on the f16 matrix
+     *   pipe: every f32 operand scaled by a power of two (per output channel / per clip) and written as two binary16 terms
+     *   (representation error <= half an f32 ulp), three partial products per multiply-add, f32 accumulation
+     *   (csrc/gemm_h2.hip); every other GEMM as conv_pipe 2.
+     * conv_pipe 2: the detector's GEMMs on the bf16 matrix pipe with every f32 operand split exactly into three
+     *   bf16 terms, six partial products per multiply-add, f32 accumulation (csrc/gemm_x3.hip) wherever K % 64 == 0 and
+     *   N % 128 == 0, f32 MFMA otherwise.
+     * conv_pipe 1: f32-input MFMA everywhere (the pipe the 16-bit kernels are tested against).
+     * All three agree with fp64 to f32 rounding level (tests/test_gpu_kernels.py::test_gemm_clip_x3).
      * readout 0: fused read-out kernel on uniform batches; 1: split-K GEMM + tail kernel + data-gradient GEMM (the
      *   path ragged batches take). */
     int conv_pipe;
@@ -326,6 +331,17 @@ int aware_gemm_clip(const float* A, int lda, const float* Bt, int ldb, const voi
  * lastpk: dev, aware_x3_pack of Wlast [16*ceil(CL/16)][N] (rows beyond CL zero).  2 <= CL <= 48.  Test / roofline entry. */
 int aware_gemm_clip_last(const float* A, int lda, const void* Bpk, const float* bias, float* C, int ldc, int B, int Tp,
                          int N, int K, float* rstd_out, const void* lastpk, float* zpart, int CL, void* stream);
+/* The same block on the DEFAULT conv pipe of the embed loop (csrc/gemm_h2.hip): the f16 matrix pipe with every f32 operand
+ * written as two binary16 terms after a power-of-two scaling (per output channel for the weights, per clip for A), three
+ * partial products per multiply-add, f32 accumulation; representation error <= 2^-24 relative per operand (half an f32 ulp).
+ * Bt: DEV [N][K] (row pitch ldb); the entry packs it and computes the clips' max |A| into `workspace`
+ * (>= aware_gemm_clip_h2_workspace_bytes).  epi 0..2 as aware_gemm_clip; lastpk / zpart / CL: as aware_gemm_clip_last (epi 1,
+ * may be NULL / 0); amax_out: dev [B][64] partial maxima of |C| per clip (N/16 written per clip) or NULL.
+ * N % 128 == 0, K % 64 == 0, K <= 1024. */
+size_t aware_gemm_clip_h2_workspace_bytes(int B, int N, int K);
+int aware_gemm_clip_h2(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc, int B, int Tp,
+                       int N, int K, int epi, float* rstd_io, const float* act, const void* lastpk, float* zpart, int CL,
+                       float* amax_out, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -116,10 +116,58 @@ def test_gemm_clip_x3(rt, B, Tp, N, K, epi):
     scale = ref.abs().amax(dim=(0, 1), keepdim=True).clamp_min(1e-30)
     e32 = ((outs[0] - ref).abs() / scale).max().item()
     ex3 = ((outs[1] - ref).abs() / scale).max().item()
-    print(f"max column-relative error: f32 MFMA {e32:.2e}, bf16x3 {ex3:.2e}")
     tol = 4e-6 * max(1.0, K / 256)
     assert e32 < tol and ex3 < tol, (e32, ex3)
     assert ex3 < 2.0 * e32 + 2e-7, (e32, ex3)          # never meaningfully worse than the f32 pipe
+    eh2 = float("nan")
+    if N % 128 == 0 and K % 64 == 0:
+        # the f16 two-term / three-product kernel (gemm_h2.hip, the embed loop's default conv pipe): same bar
+        c, rs, amax = rt.gemm_clip_h2(a.cuda(), w, None if bias is None else bias.cuda(), B, Tp, epi,
+                                      None if rstd is None else rstd.cuda(), None if act is None else act.cuda())
+        c = c.cpu().view(B, RP, N)
+        assert RP == Tp or c[:, Tp:].abs().max().item() == 0.0
+        eh2 = ((c[:, :Tp].double() - ref).abs() / scale).max().item()
+        assert eh2 < tol and eh2 < 2.0 * e32 + 2e-7, (e32, eh2)
+        # the partial maxima it leaves for the next GEMM's scale: N/16 per clip, their maximum = the clip's max |C|
+        am = amax.cpu()[:, : N // 16].max(dim=1).values
+        np.testing.assert_array_equal(am.numpy(), c.abs().amax(dim=(1, 2)).numpy())
+        if epi == 1:
+            z = (a.double() @ w.double().T).view(B, RP, N)[:, :Tp] + bias.double()
+            ref_rs = 1.0 / torch.sqrt(z.var(1, unbiased=False) + 1e-5)
+            assert ((rs.cpu().double() - ref_rs).abs() / ref_rs).max().item() < 2e-5
+    print(f"max column-relative error: f32 MFMA {e32:.2e}, bf16x3 {ex3:.2e}, f16x2 {eh2:.2e}")
+
+
+@pytest.mark.parametrize("B,Tp,N,K,epi,arange,wrange", [(16, 94, 1024, 1024, 1, 24, 20), (24, 94, 1024, 512, 2, 30, 12),
+                                                        (40, 63, 512, 128, 0, 16, 30)])
+def test_gemm_clip_h2_wide_dynamic_range(rt, B, Tp, N, K, epi, arange, wrange):
+    """The f16 two-term kernel on operands far outside binary16's range: clips whose magnitudes span 2^arange (scaled per
+    clip), weight rows spanning 2^wrange (scaled per output channel), and elements up to 2^20 below their clip's / row's
+    maximum (whose low term is subnormal or zero in binary16).  Error against fp64 relative to the column's largest value
+    per CLIP (the norm-wise bound of a dot product): at the f32 kernel's level."""
+    RP = 32 * ((Tp + 31) // 32)
+    g = torch.Generator().manual_seed(B + Tp + N + K + epi + 99)
+    a = torch.randn(B * RP, K, generator=g)
+    a *= torch.exp2(-20 * torch.rand(B * RP, K, generator=g) ** 4)                         # elements down to 2^-20 of the clip scale
+    a = (a.view(B, RP, K) * torch.exp2(torch.randint(-arange, 4, (B, 1, 1), generator=g).float())).reshape(B * RP, K)
+    a.view(B, RP, K)[:, Tp:] = 0
+    w = torch.randn(N, K, generator=g) * torch.exp2(-20 * torch.rand(N, K, generator=g) ** 4)
+    w = w * torch.exp2(torch.randint(-wrange, 4, (N, 1), generator=g).float()) / K ** 0.5
+    bias = None
+    act = torch.randn(B * RP, N, generator=g) if epi == 2 else None
+    rstd = torch.rand(B, N, generator=g) + 0.5 if epi == 2 else None
+    if epi == 1:
+        bias = torch.zeros(N)
+    ref = _block_reference(a, w, torch.zeros(N) if epi != 2 else None, act, rstd, B, RP, Tp, epi)
+    c0, _ = rt.gemm_clip(a.cuda(), w.cuda(), None if bias is None else bias.cuda(), B, Tp, epi,
+                         None if rstd is None else rstd.cuda(), None if act is None else act.cuda(), 0)
+    c2 = rt.gemm_clip_h2(a.cuda(), w, None if bias is None else bias.cuda(), B, Tp, epi,
+                         None if rstd is None else rstd.cuda(), None if act is None else act.cuda())[0]
+    scale = ref.abs().amax(dim=1, keepdim=True).clamp_min(1e-300)                          # per clip and column
+    e32 = ((c0.cpu().view(B, RP, N)[:, :Tp].double() - ref).abs() / scale).max().item()
+    eh2 = ((c2.cpu().view(B, RP, N)[:, :Tp].double() - ref).abs() / scale).max().item()
+    print(f"max error relative to the (clip, column) maximum: f32 MFMA {e32:.2e}, f16x2 {eh2:.2e}")
+    assert eh2 < 4e-6 * max(1.0, K / 256) and eh2 < 2.0 * e32 + 2e-7, (e32, eh2)
 
 
 @pytest.mark.parametrize("B,Tp,N,K,CL", [(16, 94, 1024, 1024, 40), (21, 94, 1024, 1024, 40), (64, 94, 1024, 1024, 40),
@@ -153,6 +201,18 @@ def test_gemm_clip_last_partials(rt, B, Tp, N, K, CL):
     print(f"block output err {err:.2e}; last-conv partial-sum err {ez:.2e}")
     assert ez < 4e-6 * max(1.0, N / 256) + 8 * err, ez
     assert RP == Tp or zsum[:, Tp:].abs().max().item() == 0.0
+    # the same block + partials on the f16 two-term kernel (gemm_clip_h2_kernel<RG, X3_FWD_LAST>: what the loop runs by default)
+    c2, rs2, _, zp2 = rt.gemm_clip_h2(a.cuda(), w, bias.cuda(), B, Tp, 1, None, None, w_last=wl)
+    c2 = c2.cpu().view(B, RP, N)
+    assert RP == Tp or c2[:, Tp:].abs().max().item() == 0.0
+    err2 = ((c2[:, :Tp].double() - ref).abs() / scale).max().item()
+    assert err2 < tol, err2
+    assert ((rs2.cpu().double() - ref_rs).abs() / ref_rs).max().item() < 2e-5
+    zsum2 = zp2.cpu().double().sum(0).view(B, RP, CL)
+    ez2 = ((zsum2[:, :Tp] - zref).abs() / zs).max().item()
+    print(f"f16x2: block output err {err2:.2e}; last-conv partial-sum err {ez2:.2e}")
+    assert ez2 < 4e-6 * max(1.0, N / 256) + 8 * err2, ez2
+    assert RP == Tp or zsum2[:, Tp:].abs().max().item() == 0.0
 
 
 def test_x3_split_is_exact(rt):
@@ -368,26 +428,33 @@ def test_embed_full_1s_bits_exact(rt, plan, det, O):
     assert bool(((bc >= lo) & (bc <= hi)).all())
 
 
-def test_first_iteration_x3_vs_f32_pipe(rt, plan, det, O):
-    """Whole first loop body with the conv blocks on the bf16x3 kernel (default) and on the f32-MFMA kernel:
-    loss, prediction and dL/dcoef agree to f32 rounding."""
-    lengths = [48000] * 3
+@pytest.mark.parametrize("nclips", [3, 40])
+def test_first_iteration_x3_vs_f32_pipe(rt, plan, det, O, nclips):
+    """Whole first loop body with the conv blocks on the three matrix pipes -- f16 two-term (default; takes the conv blocks
+    from 32 clips on, below that it is the bf16x3 configuration), bf16 three-term, f32-input MFMA: loss, prediction and
+    dL/dcoef agree to f32 rounding.  (40 clips: the f16 kernel with its scales from the clip_amax pre-pass, the mel block in
+    two launches.)"""
+    lengths = [48000] * nclips
     pairs = [make_clip(40 + i, n) for i, n in enumerate(lengths)]
     wm = np.stack([O.bits_to_bipolar(p[1]) for p in pairs]).astype(np.float32)
     batch = rt.Batch(lengths)
-    res = []
-    for pipe in ("bf16x3", "f32"):
+    res = {}
+    for pipe in ("f16x2", "bf16x3", "f32"):
         sess = rt.EmbedSession(plan, det, batch, use_graph=False, conv_pipe=pipe)
         sess.begin(batch.pack([p[0] for p in pairs]), torch.from_numpy(wm).cuda())
         g = sess.gradient()
         torch.cuda.synchronize()
-        res.append((g.cpu().double(), sess.loss.cpu().numpy().copy(), sess.pred.cpu().numpy().copy()))
-    (g4, l4, p4), (g0, l0, p0) = res
-    assert np.max(np.abs(l4 - l0)) < 2e-6
-    assert np.max(np.abs(p4 - p0)) < 2e-6
-    rel = ((g4 - g0).norm() / g0.norm()).item()
-    print("relative L2 difference of the gradients, bf16x3 vs f32 MFMA:", rel)
-    assert rel < 2e-5, rel
+        res[pipe] = (g.cpu().double(), sess.loss.cpu().numpy().copy(), sess.pred.cpu().numpy().copy())
+    g0, l0, p0 = res["f32"]
+    for pipe in ("f16x2", "bf16x3"):
+        g4, l4, p4 = res[pipe]
+        assert np.max(np.abs(l4 - l0)) < 2e-6
+        assert np.max(np.abs(p4 - p0)) < 2e-6
+        sl = [slice(batch.frame_offsets[i], batch.frame_offsets[i + 1]) for i in range(nclips)]
+        rel = np.asarray([((g4[s_] - g0[s_]).norm() / g0[s_].norm()).item() for s_ in sl])
+        print(f"relative L2 difference of the gradients per clip, {pipe} vs f32 MFMA: median {np.median(rel):.2e} max {rel.max():.2e}")
+        # (a clip with a LeakyReLU argument within rounding of its kink may take the other sub-gradient: isolated, finite)
+        assert np.median(rel) < 2e-5 and int((rel > 2e-5).sum()) <= max(1, nclips // 20), rel
 
 
 @pytest.mark.parametrize("n", [16000, 48000, 33000, 64000])
