@@ -66,6 +66,12 @@ class EmbedConfig(C.Structure):
                 ("dsp_path", C.c_int), ("l1_weight", C.c_float)]
 
 
+class OptimizerConfig(C.Structure):
+    _fields_ = [("kind", C.c_int), ("hyp", C.c_float * 8), ("weight_decay", C.c_double), ("table", C.POINTER(C.c_double)),
+                ("plateau", C.c_int), ("patience", C.c_int), ("factor", C.c_double), ("threshold", C.c_double),
+                ("min_lr", C.c_double), ("eps", C.c_double), ("lr0", C.c_double)]
+
+
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 _pi = C.POINTER(C.c_int)
 
@@ -109,6 +115,8 @@ SIGNATURES = {
     "aware_embed_workspace_bytes": (_sz, [_vp, _vp]),
     "aware_embed_create": (_i, [C.POINTER(_vp), _vp, _vp, _vp, C.POINTER(EmbedConfig), _vp, _sz, _vp]),
     "aware_embed_destroy": (None, [_vp]),
+    "aware_embed_set_optimizer": (_i, [_vp, C.POINTER(OptimizerConfig), _vp]),
+    "aware_opt_clamp_step": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp]),
     "aware_embed_begin": (_i, [_vp, _vp, _vp, _vp]),
     "aware_embed_iterate": (_i, [_vp, _i, _vp]),
     "aware_embed_profile": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
@@ -125,6 +133,7 @@ SIGNATURES = {
     "aware_snr": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "aware_gaussian_noise": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _f, _vp, _vp]),
     "aware_spectral_quantize": (_i, [_vp, _i, _f, _f, _vp]),
+    "aware_spectral_quantize_bwd": (_i, [_vp, _vp, _vp, _i, _f, _f, _vp]),
     "aware_gemm_nt_variant": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "aware_x3_packed_bytes": (_sz, [_i, _i]),
     "aware_x3_pack": (_i, [_vp, _i, _i, _vp]),

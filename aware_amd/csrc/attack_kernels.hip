@@ -482,6 +482,58 @@ __global__ __launch_bounds__(256) void spectral_quantize_kernel(cf* __restrict__
         X[k] = mk(x.x * sc, x.y * sc);
     }
 }
+// Backward of the surrogate as a DIFFERENTIABLE op (BASELINE north_star "differentiable MP3-like quantisation surrogates"):
+// Y = Q(|X|) X/|X|.  The quantiser's staircase has zero derivative almost everywhere, so the magnitude path is straight-through
+// (dQ/d|X| := 1 on kept bins, 0 on bins dropped below the floor; the frame maximum is treated as a constant), the phase path
+// is exact (Y keeps X's phase, scaled by Q/|X|):   gX = u [ keep Re(G conj u) + i (Q/|X|) Im(G conj u) ],  u = X/|X|.
+// X: the spectrum BEFORE quantisation; G = dL/dRe Y + i dL/dIm Y; specified by oracle/aware_oracle.py::mp3_surrogate_spectrum.
+__global__ __launch_bounds__(256) void spectral_quantize_bwd_kernel(const cf* __restrict__ spec, const cf* __restrict__ gout,
+                                                                     cf* __restrict__ gin, int nframes, float step_db, float floor_db) {
+    const int frame = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (frame >= nframes) return;
+    const cf* X = spec + (size_t)frame * 520;
+    const cf* G = gout + (size_t)frame * 520;
+    cf* O = gin + (size_t)frame * 520;
+    cf xv[9];
+    float mg[9];
+    float mx = 0.f;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        const int k = lane + 64 * r;
+        mg[r] = 0.f;
+        xv[r] = mk(0.f, 0.f);
+        if (k <= 512) { xv[r] = X[k]; mg[r] = sqrtf(xv[r].x * xv[r].x + xv[r].y * xv[r].y); }
+        mx = fmaxf(mx, mg[r]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    mx = fmaxf(mx, 1e-12f);
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        const int k = lane + 64 * r;
+        if (k > 512) continue;
+        const float m = fmaxf(mg[r], 1e-12f);
+        const float db = 20.0f * log10f(m / mx);
+        const float q = rintf(db / step_db) * step_db;
+        const bool keep = !(db < floor_db) && mg[r] > 0.f;
+        const float sc = keep ? mx * powf(10.0f, q / 20.0f) / mg[r] : 0.f;
+        const cf g = G[k];
+        cf o = mk(0.f, 0.f);
+        if (keep) {
+            const float ux = xv[r].x / mg[r], uy = xv[r].y / mg[r];
+            const float re = g.x * ux + g.y * uy;                 // Re(G conj u)
+            const float im = (g.y * ux - g.x * uy) * sc;          // (Q/|X|) Im(G conj u)
+            o = mk(ux * re - uy * im, uy * re + ux * im);         // u (re + i im)
+        }
+        O[k] = o;
+    }
+}
+void launch_spectral_quantize_bwd(const void* spec, const void* gout, void* gin, int nframes, float step_db, float floor_db,
+                                  hipStream_t st) {
+    hipLaunchKernelGGL(spectral_quantize_bwd_kernel, dim3((nframes + 3) / 4), dim3(256), 0, st, (const cf*)spec, (const cf*)gout,
+                       (cf*)gin, nframes, step_db, floor_db);
+}
 void launch_spectral_quantize(void* spec, int nframes, float step_db, float floor_db, hipStream_t st) {
     hipLaunchKernelGGL(spectral_quantize_kernel, dim3((nframes + 3) / 4), dim3(256), 0, st, (cf*)spec, nframes, step_db,
                        floor_db);

@@ -1006,6 +1006,17 @@ struct aware_embed {
     hipGraphExec_t gexec = nullptr, gexecN = nullptr;
     hipStream_t cap = nullptr;        // private stream used only to record the graph
     int steps_done = 0;               // optimiser steps since aware_embed_begin (host mirror of *step)
+    // optimiser / scheduler other than the model card's (aware_embed_set_optimizer): the step runs as its own launch
+    struct {
+        bool active = false;
+        int kind = 0, plateau = 0, patience = 0;
+        float hyp[8] = {0};
+        double wd = 0, factor = 0, threshold = 0, min_lr = 0, eps = 0, lr0 = 0;
+        double* d_tab = nullptr;      // [num_iterations][5]
+        double* d_lr = nullptr;       // [B] per-clip learning rate (plateau)
+        double* d_state = nullptr;    // [B][3] plateau state
+        std::vector<double> lr_init, state_init;
+    } opt;
 };
 
 static size_t embed_bytes(const aware_batch* b, const aware_detector* d, int iters) {
@@ -1017,7 +1028,7 @@ static size_t embed_bytes(const aware_batch* b, const aware_detector* d, int ite
     bytes += (size_t)b->NF * kFS * sizeof(float) + (size_t)b->B * b->pstride * 8 + (size_t)b->B * sizeof(float) + 1024;   // L1 term
     bytes += (size_t)b->NP * d->maxc * sizeof(float) * 2;
     bytes += (size_t)b->B * (3 * d->nbits + 8) * sizeof(float);
-    bytes += (size_t)(iters + 1) * sizeof(float4);
+    bytes += (size_t)(iters + 1) * sizeof(float4) + (size_t)iters * 5 * sizeof(double) + (size_t)b->B * 4 * sizeof(double) + 1024;
     bytes += (size_t)b->B * b->pstride * 8 * 3;
     return bytes + 256 * 40;
 }
@@ -1050,6 +1061,13 @@ extern "C" int aware_nadam_clamp_step(float* param, const float* grad, float* ex
     if (!param || !grad || !exp_avg || !exp_avg_sq || !coef3 || n < 1) return AWARE_E_BADARG;
     launch_nadam_clamp(param, grad, exp_avg, exp_avg_sq, lo, hi, n, coef3[0], coef3[1], coef3[2], beta1, beta2, eps,
                        (hipStream_t)stream);
+    LAUNCHCHK();
+    return AWARE_OK;
+}
+extern "C" int aware_opt_clamp_step(int kind, float* param, const float* grad, float* state1, float* state2, const float* lo,
+                                    const float* hi, size_t n, const float* coef4, const float* hyp8, void* stream) {
+    if (kind < 0 || kind > 7 || !param || !grad || !state1 || !state2 || !coef4 || !hyp8 || n < 1) return AWARE_E_BADARG;
+    launch_opt_clamp(kind, param, grad, state1, state2, lo, hi, n, coef4, hyp8, (hipStream_t)stream);
     LAUNCHCHK();
     return AWARE_OK;
 }
@@ -1115,6 +1133,9 @@ extern "C" int aware_embed_create(aware_embed** out, const aware_plan* plan, con
     e->pmaxY = c.take<unsigned long long>((size_t)b->B * b->pstride);
     e->pdot = c.take<double>((size_t)b->B * b->pstride);
     e->c0 = c.take<float>(nsp);
+    e->opt.d_tab = c.take<double>((size_t)cfg->num_iterations * 5);
+    e->opt.d_lr = c.take<double>(b->B);
+    e->opt.d_state = c.take<double>((size_t)b->B * 3);
     if (cfg->loss == AWARE_LOSS_PUSH_L1) {
         // the L1 term lives in the streaming DSP kernels only
         if (cfg->dsp_path != 0 || !stream_supported(plan->dev)) { delete e; return AWARE_E_UNSUPPORTED; }
@@ -1159,8 +1180,32 @@ extern "C" int aware_embed_create(aware_embed** out, const aware_plan* plan, con
     *out = e;
     return AWARE_OK;
 }
+// The third seam of the reference: optimiser / scheduler registries selected by YAML strings (embedding/optimizers.py:3-20,
+// schedulers.py:3-16).  The host computes the per-step scalars of the chosen torch optimiser under the chosen learning-rate
+// schedule (aware_amd/embedding/optimizers.py); the device applies them (opt_clamp_update, dsp_args.hpp).
+extern "C" int aware_embed_set_optimizer(aware_embed* e, const aware_optimizer_config* oc, void* stream) {
+    if (!e || !oc || oc->kind < 0 || oc->kind > 7 || !oc->table) return AWARE_E_BADARG;
+    if (e->gexec) return AWARE_E_BADARG;                 // before the first aware_embed_iterate (the graphs are recorded then)
+    if (oc->plateau && (!(oc->factor < 1.0) || oc->patience < 0)) return AWARE_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int n = e->cfg.num_iterations, B = e->b->B;
+    auto& o = e->opt;
+    HIPCHK(hipMemcpyAsync(o.d_tab, oc->table, (size_t)n * 5 * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    o.kind = oc->kind; o.plateau = oc->plateau; o.patience = oc->patience;
+    for (int i = 0; i < 8; ++i) o.hyp[i] = oc->hyp[i];
+    o.wd = oc->weight_decay; o.factor = oc->factor; o.threshold = oc->threshold; o.min_lr = oc->min_lr; o.eps = oc->eps;
+    o.lr0 = oc->lr0;
+    o.lr_init.assign(B, oc->lr0);
+    o.state_init.assign((size_t)B * 3, 0.0);
+    for (int b = 0; b < B; ++b) o.state_init[3 * b] = (double)INFINITY;
+    o.active = true;
+    return AWARE_OK;
+}
+
 extern "C" void aware_embed_destroy(aware_embed* e) {
     if (!e) return;
+
     if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
     if (e->graph) (void)hipGraphDestroy(e->graph);
     if (e->gexecN) (void)hipGraphExecDestroy(e->gexecN);
@@ -1183,6 +1228,7 @@ extern "C" void* aware_embed_buffer(aware_embed* e, int which) {
         case 8: return e->step;
         case 9: return e->yraw;
         case 10: return e->mag;
+        case 11: return e->opt.active ? e->opt.d_lr : nullptr;      // per-clip learning rate (double; ReduceLROnPlateau state)
         default: return nullptr;
     }
 }
@@ -1217,6 +1263,10 @@ extern "C" int aware_embed_begin(aware_embed* e, const float* audio, const float
     HIPCHK(hipMemsetAsync(e->step, 0, 4 * sizeof(int), st));
     // best_loss = +inf (0x7F800000)
     HIPCHK(hipMemsetD32Async((hipDeviceptr_t)e->best_loss, 0x7F800000, b->B, st));
+    if (e->opt.active) {
+        HIPCHK(hipMemcpyAsync(e->opt.d_lr, e->opt.lr_init.data(), (size_t)b->B * sizeof(double), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(e->opt.d_state, e->opt.state_init.data(), (size_t)b->B * 3 * sizeof(double), hipMemcpyHostToDevice, st));
+    }
     e->steps_done = 0;
     return AWARE_OK;
 }
@@ -1271,12 +1321,24 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
     LA.adjoint = 1; LA.yraw = e->yraw; LA.pdot = e->pdot; LA.phasor = e->P;
     LA.coef = e->coef; LA.mom = e->mom; LA.vel = e->vel; LA.lo = e->lo; LA.hi = e->hi; LA.best = e->best;
     LA.improved = e->improved; LA.sched = e->sched; LA.sched_len = e->cfg.num_iterations + 1; LA.step = e->step;
-    LA.grad_out = grad_out; LA.do_step = do_step;
+    // (an optimiser / schedule set by aware_embed_set_optimizer steps in its own launch below: the adjoint then only
+    //  delivers the gradient, into gmag -- consumed by the synthesis adjoint by now)
+    const bool own_step = do_step && e->opt.active;
+    LA.grad_out = own_step ? e->gmag : grad_out; LA.do_step = own_step ? 0 : do_step;
     memcpy(LA.hyp, e->hyp, sizeof(LA.hyp));
     LA.gpad = e->gpad; LA.c0 = e->c0; LA.box_ratio = (float)pow(10.0, -(double)e->cfg.tolerance_db / 20.0);
     LA.l1_weight = e->pl1 ? e->cfg.l1_weight : 0.f;
     run_analysis(LA, dsp, st);
     LAUNCHCHK(); PROF(K_ANALYSIS_ADJ);
+    if (own_step) {
+        const auto& o = e->opt;
+        launch_opt_rows(o.kind, e->coef, e->gmag, e->mom, e->vel, e->c0, LA.box_ratio, e->best, e->improved, b->d_frame_off, b->B,
+                        b->NF, o.d_tab, e->cfg.num_iterations, e->step, o.plateau ? o.d_lr : nullptr, o.wd, o.hyp,
+                        e->plan->dev.nband, st);
+        if (o.plateau)
+            launch_plateau(e->loss, o.d_state, o.d_lr, b->B, o.factor, o.patience, o.threshold, o.min_lr, o.eps, st);
+        LAUNCHCHK(); PROF(K_MISC);
+    }
     return AWARE_OK;
 }
 
@@ -1478,6 +1540,14 @@ extern "C" int aware_phase_vocoder(const void* spec_in, const int* frame_off_in,
 extern "C" int aware_spectral_quantize(void* spec, int n_frames, float step_db, float floor_db, void* stream) {
     if (!spec || n_frames < 1 || !(step_db > 0.f)) return AWARE_E_BADARG;
     launch_spectral_quantize(spec, n_frames, step_db, floor_db, (hipStream_t)stream);
+    LAUNCHCHK();
+    return AWARE_OK;
+}
+
+extern "C" int aware_spectral_quantize_bwd(const void* spec_in, const void* grad_out, void* grad_in, int n_frames, float step_db,
+                                           float floor_db, void* stream) {
+    if (!spec_in || !grad_out || !grad_in || n_frames < 1 || !(step_db > 0.f)) return AWARE_E_BADARG;
+    launch_spectral_quantize_bwd(spec_in, grad_out, grad_in, n_frames, step_db, floor_db, (hipStream_t)stream);
     LAUNCHCHK();
     return AWARE_OK;
 }

@@ -30,6 +30,65 @@ __device__ __forceinline__ void nadam_clamp_update(float& p, float& mo, float& v
     p = fminf(fmaxf(p, blo), bhi);
 }
 
+// The other optimisers of the reference's registry (embedding/optimizers.py:3-20), as one element-wise update with the
+// arithmetic of torch's single-tensor implementations (torch/optim/{adam,sgd,rmsprop,adagrad,adamax,adadelta}.py -- what the
+// reference's get_optimizer(name, [coeffs], **params).step() runs on its CPU tensors), followed by the clamp to the box.
+// c: per-step scalars computed on the host (learning-rate schedule included), h: hyper-parameters:
+//   kind 1 adam / 2 adamw  c.x = -lr/bc1, c.z = sqrt(bc2), c.w = 1 - lr*wd (adamw);  h0 = 1-beta1, h1 = beta2, h2 = 1-beta2, h3 = eps
+//   kind 3 sgd             c.x = -lr, c.y = 1 on the first step (buf = grad);  h0 = momentum, h5 = nesterov, h6 = 1-dampening
+//   kind 4 rmsprop         c.x = -lr;  h1 = alpha, h2 = 1-alpha, h3 = eps
+//   kind 5 adagrad         c.x = -lr/(1+(t-1)*lr_decay);  h3 = eps
+//   kind 6 adamax          c.x = -lr/bc1;  h0 = 1-beta1, h1 = beta2, h3 = eps
+//   kind 7 adadelta        c.x = -lr;  h1 = rho, h2 = 1-rho, h3 = eps     (mo holds acc_delta, ve square_avg)
+//   kind 0 nadam           c.x, c.y, c.z as nadam_clamp_update (c.z = bc2);  h0..h3 as adam
+//   all but adamw: h4 = weight_decay (L2: grad += wd * param)
+enum { OPT_NADAM = 0, OPT_ADAM = 1, OPT_ADAMW = 2, OPT_SGD = 3, OPT_RMSPROP = 4, OPT_ADAGRAD = 5, OPT_ADAMAX = 6, OPT_ADADELTA = 7 };
+struct OptHyp { float h[8]; };
+__device__ __forceinline__ void opt_clamp_update(int kind, float& p, float& mo, float& ve, float g, float blo, float bhi,
+                                                 const float4& c, const OptHyp& H) {
+    const float* h = H.h;
+    if (kind == OPT_ADAMW) p = p * c.w;
+    else if (h[4] != 0.f) g = g + h[4] * p;
+    if (kind == OPT_NADAM) {
+        mo = mo + h[0] * (g - mo);
+        ve = ve * h[1] + (h[2] * g) * g;
+        const float den = sqrtf(ve / c.z) + h[3];
+        p = p + (c.x * g) / den;
+        p = p + (c.y * mo) / den;
+    } else if (kind == OPT_ADAM || kind == OPT_ADAMW) {
+        mo = mo + h[0] * (g - mo);
+        ve = ve * h[1] + (h[2] * g) * g;
+        const float den = sqrtf(ve) / c.z + h[3];
+        p = p + (c.x * mo) / den;
+    } else if (kind == OPT_SGD) {
+        float d = g;
+        if (h[0] != 0.f) {
+            mo = (c.y != 0.f) ? g : mo * h[0] + h[6] * g;
+            d = (h[5] != 0.f) ? g + h[0] * mo : mo;
+        }
+        p = p + c.x * d;
+    } else if (kind == OPT_RMSPROP) {
+        ve = ve * h[1] + (h[2] * g) * g;
+        const float avg = sqrtf(ve) + h[3];
+        p = p + (c.x * g) / avg;
+    } else if (kind == OPT_ADAGRAD) {
+        ve = ve + g * g;
+        const float sd = sqrtf(ve) + h[3];
+        p = p + (c.x * g) / sd;
+    } else if (kind == OPT_ADAMAX) {
+        mo = mo + h[0] * (g - mo);
+        ve = fmaxf(ve * h[1], fabsf(g) + h[3]);
+        p = p + (c.x * mo) / ve;
+    } else {      // OPT_ADADELTA
+        ve = ve * h[1] + (h[2] * g) * g;
+        const float sd = sqrtf(ve + h[3]);
+        const float delta = sqrtf(mo + h[3]) / sd * g;
+        mo = mo * h[1] + (h[2] * delta) * delta;
+        p = p + c.x * delta;
+    }
+    p = fminf(fmaxf(p, blo), bhi);
+}
+
 // The tolerance box of a coefficient (embedding/multibit_embedder.py:157-160): d = c0 * 10^(-tol/20),
 // lo = max(c0 - d, 0), hi = c0 + d.  Explicitly rounded operations (no fused multiply-add), so that the kernel that
 // stores the box and the kernel that recomputes it from c0 agree bit for bit.

@@ -137,13 +137,15 @@ __device__ __forceinline__ void h2_tile_gemm(const float* __restrict__ A, int ld
     constexpr int PLANE = MT * FRAG;
     constexpr int KSS = 2 * PLANE;        // one K32 step
     constexpr int BUF = 2 * KSS;          // one K tile (BK = 64)
-    constexpr int NCH = (RG * 256 + NT - 1) / NT;     // 8-float chunks of the A tile per thread
+    // A staging: pass i covers rows 32 i .. 32 i + 31 of the K tile; thread -> (row tid >> 4, 4 floats at k = 4 (tid & 15)):
+    // one fully coalesced 16-byte load per lane (16 lanes = one 256-byte row segment) and one 8-byte LDS store per plane
+    constexpr int NPASS = RG;
 
     bm = __builtin_amdgcn_readfirstlane(bm);
     bn = __builtin_amdgcn_readfirstlane(bn);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, kg = lane >> 4;
-    const int srow = tid >> 3, sc = tid & 7;          // chunk i of this thread: row srow + 64 i, k = 8 sc
+    const int srow = tid >> 4, k4 = tid & 15, sc = k4 >> 1;      // sc: the 8-wide k chunk (one lane's share of a fragment)
     unsigned rb[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) rb[t] = (unsigned)(t * KSS + kg * 256 + ((r16 ^ (4 * t + kg)) * 16));
@@ -152,50 +154,63 @@ __device__ __forceinline__ void h2_tile_gemm(const float* __restrict__ A, int ld
     const int nkt = K >> 6;
     const u32x4* bp = Bpk + ((size_t)((bn >> 4) + wave) * KS2) * 128;                // uniform; + lane per thread
     const float* ap = A + (size_t)bm * lda;                                          // uniform
-    unsigned roff[NCH];
+    unsigned roff[NPASS];
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) roff[i] = (unsigned)(min(srow + (NT / 8) * i, row_limit - 1) * lda + sc * 8);
+    for (int i = 0; i < NPASS; ++i) roff[i] = (unsigned)(min(srow + 32 * i, row_limit - 1) * lda + k4 * 4);
+    // LDS slot of this thread's 4 k-values of row srow (+ 32 i: two fragment images further): the XOR of the row slot with
+    // the k chunk keeps the 16 lanes of a row on 16 distinct 8-byte slots of a 128-byte bank row
+    const unsigned woff = (unsigned)((sc >> 2) * KSS + (srow >> 4) * FRAG + (sc & 3) * 256 + (((srow & 15) ^ sc) * 16) + (k4 & 1) * 8);
 
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    float4 ra[NCH][2];
-    auto chunk_ok = [&](int i) { return (RG * 256) % NT == 0 || tid + NT * i < RG * 256; };
+#ifndef H2_ABL
+#define H2_ABL 0          // timing-only ablations of the K loop (tools/h2_ablate.sh); results are invalid when non-zero
+#endif
+    bool in_loop = false;
+    float4 ra[NPASS];
     auto gload_c = [&](int i, int kt) {
-        if (chunk_ok(i)) {
-            const float* p = ap + kt * 64;
-            ra[i][0] = *reinterpret_cast<const float4*>(p + roff[i]);
-            ra[i][1] = *reinterpret_cast<const float4*>(p + roff[i] + 4);
-        }
+        if ((H2_ABL & 32) && in_loop) return;
+        ra[i] = *reinterpret_cast<const float4*>(ap + kt * 64 + roff[i]);
     };
     auto split_store_c = [&](int i, unsigned boff) {
-        if (chunk_ok(i)) {
-            const int row = srow + (NT / 8) * i;
-            uint4 qh, ql;
-            h2_split_pair(ra[i][0].x, ra[i][0].y, ascale, qh.x, ql.x);
-            h2_split_pair(ra[i][0].z, ra[i][0].w, ascale, qh.y, ql.y);
-            h2_split_pair(ra[i][1].x, ra[i][1].y, ascale, qh.z, ql.z);
-            h2_split_pair(ra[i][1].z, ra[i][1].w, ascale, qh.w, ql.w);
-            unsigned char* d = lds + boff + (sc >> 2) * KSS + (row >> 4) * FRAG + (sc & 3) * 256 + (((row & 15) ^ sc) * 16);
-            *reinterpret_cast<uint4*>(d) = qh;
-            *reinterpret_cast<uint4*>(d + PLANE) = ql;
+        uint2 qh, ql;
+        if ((H2_ABL & 1) && in_loop) {
+            qh = make_uint2(__float_as_uint(ra[i].x), __float_as_uint(ra[i].y));
+            ql = make_uint2(__float_as_uint(ra[i].z), __float_as_uint(ra[i].w));
+        } else {
+            h2_split_pair(ra[i].x, ra[i].y, ascale, qh.x, ql.x);
+            h2_split_pair(ra[i].z, ra[i].w, ascale, qh.y, ql.y);
+        }
+        unsigned char* d = lds + boff + woff + i * 2 * FRAG;
+        if ((H2_ABL & 2) && in_loop) {
+            asm volatile("" :: "v"(qh.x), "v"(qh.y), "v"(ql.x), "v"(ql.y));
+        } else {
+            *reinterpret_cast<uint2*>(d) = qh;
+            *reinterpret_cast<uint2*>(d + PLANE) = ql;
         }
     };
     u32x4 bq[2][2];
     auto loadB = [&](int set, int ks2) {
+        if ((H2_ABL & 8) && in_loop) return;
         ks2 = ks2 < KS2 ? ks2 : KS2 - 1;
 #pragma unroll
         for (int p = 0; p < 2; ++p) bq[set][p] = (bp + ((size_t)ks2 * 2 + p) * 64)[(unsigned)lane];
     };
-    auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto lds_barrier = [&]() {
+        if ((H2_ABL & 16) && in_loop) return;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
     // A fragments: the h plane is double-buffered (the next quarter's h fragments are requested a whole quarter -- 3 MH MFMAs
     // -- ahead), the l plane single-buffered and refilled right after its only product of the quarter (2 MH MFMAs ahead)
     f16x8 ah[2][MH], al[MH];
     auto read_h = [&](int set, unsigned off) {
+        if ((H2_ABL & 4) && in_loop) return;
 #pragma unroll
         for (int m = 0; m < MH; ++m) ah[set][m] = *reinterpret_cast<const f16x8*>(lds + off + m * FRAG);
     };
     auto read_l = [&](unsigned off) {
+        if ((H2_ABL & 4) && in_loop) return;
 #pragma unroll
         for (int m = 0; m < MH; ++m) al[m] = *reinterpret_cast<const f16x8*>(lds + off + PLANE + m * FRAG);
     };
@@ -205,15 +220,20 @@ __device__ __forceinline__ void h2_tile_gemm(const float* __restrict__ A, int ld
 #define H2_PIN(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) gload_c(i, 0);
+    for (int i = 0; i < NPASS; ++i) gload_c(i, 0);
     loadB(0, 0);
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) split_store_c(i, 0);
+    for (int i = 0; i < NPASS; ++i) split_store_c(i, 0);
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) gload_c(i, nkt > 1 ? 1 : 0);
+    for (int i = 0; i < NPASS; ++i) gload_c(i, nkt > 1 ? 1 : 0);
     lds_barrier();
     read_h(0, rb[0]);
     read_l(rb[0]);
+    if (H2_ABL) {            // (ablations: the second h set and the second B set are never refilled -- give them values)
+        read_h(1, rb[0]);
+        bq[1][0] = bq[0][0]; bq[1][1] = bq[0][1];
+    }
+    in_loop = true;
     for (int kt = 0; kt < nkt; ++kt) {
         const unsigned cur = (kt & 1) * BUF, nxt = BUF - cur;
         const int ktn = kt + 2 < nkt ? kt + 2 : nkt - 1;
@@ -221,7 +241,7 @@ __device__ __forceinline__ void h2_tile_gemm(const float* __restrict__ A, int ld
         for (int q = 0; q < 4; ++q) {                 // quarter = (K32 step q>>1, row half q&1)
             const int t = q >> 1, hf = q & 1;
             if (hf == 0) loadB((t + 1) & 1, kt * 2 + t + 1);          // B fragments one K32 step ahead
-            if (q < NCH) {
+            if (q < NPASS) {
                 split_store_c(q, nxt);
                 gload_c(q, ktn);
             }

@@ -188,6 +188,14 @@ void launch_normalize_bwd(const float* x, const float* g, float* dx, const int* 
 void launch_nadam_clamp(float* p, const float* g, float* m, float* v, const float* lo, const float* hi, size_t n, float c_grad,
                         float c_mom, float bias_corr2, float beta1, float beta2, float eps, hipStream_t st);
 
+void launch_opt_clamp(int kind, float* p, const float* g, float* m, float* v, const float* lo, const float* hi, size_t n,
+                      const float* c4, const float* h8, hipStream_t st);
+void launch_opt_rows(int kind, float* coef, const float* grad, float* mom, float* vel, const float* c0, float ratio, float* best,
+                     const int* improved, const int* frame_off, int B, int NF, const double* tab, int tab_len, const int* step,
+                     const double* lr_clip, double wd, const float* h8, int nband, hipStream_t st);
+void launch_plateau(const float* loss, double* state, double* lr_clip, int B, double factor, int patience, double threshold,
+                    double min_lr, double eps, hipStream_t st);
+
 // ---- attack_kernels.hip -----------------------------------------------------------------
 void launch_pcm_quantize(const float* in, float* out, const int* off, const int* len, const unsigned long long* pmax,
                          const int* pcount, int pstride, float q, float lo, float hi, int B, int max_len,
@@ -206,6 +214,8 @@ void launch_snr(const float* a, const int* a_off, const float* b, const int* b_o
                 hipStream_t st);
 void launch_phase_vocoder(const void* in, const int* fin, void* out, const int* fout, double rate, int B, hipStream_t st);
 void launch_spectral_quantize(void* spec, int nframes, float step_db, float floor_db, hipStream_t st);
+void launch_spectral_quantize_bwd(const void* spec, const void* gout, void* gin, int nframes, float step_db, float floor_db,
+                                  hipStream_t st);
 void launch_decimate_interp(const float* in, const int* off, const int* len, double* out, int k, int B, int max_len,
                             hipStream_t st);
 void launch_segment_copy(const float* in, const int* in_off, float* out, const int* out_off, const int* out_len,

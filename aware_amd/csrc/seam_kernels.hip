@@ -106,6 +106,99 @@ __global__ __launch_bounds__(256) void nadam_clamp_kernel(float* __restrict__ p,
     }
 }
 
+// Any optimiser of opt_clamp_update (dsp_args.hpp) + clamp, flat arrays, per-step scalars from the host: the generic form of
+// nadam_clamp_kernel for the plug-in seam.
+__global__ __launch_bounds__(256) void opt_clamp_kernel(int kind, float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v,
+                                                        const float* __restrict__ lo, const float* __restrict__ hi, size_t n,
+                                                        float4 c, OptHyp H) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float mo = m[i], ve = v[i], pv = p[i];
+        opt_clamp_update(kind, pv, mo, ve, g[i], lo ? lo[i] : -INFINITY, hi ? hi[i] : INFINITY, c, H);
+        m[i] = mo; v[i] = ve; p[i] = pv;
+    }
+}
+void launch_opt_clamp(int kind, float* p, const float* g, float* m, float* v, const float* lo, const float* hi, size_t n,
+                      const float* c4, const float* h8, hipStream_t st) {
+    OptHyp H;
+    for (int i = 0; i < 8; ++i) H.h[i] = h8[i];
+    const size_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(opt_clamp_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, st, kind, p, g, m, v, lo, hi,
+                       n, make_float4(c4[0], c4[1], c4[2], c4[3]), H);
+}
+
+// The optimiser step of an embed session that does not run in the fused epilogue of the analysis adjoint (any optimiser but
+// NAdam, or a learning rate that differs per clip): one workgroup per spectral row [256 columns] of the batch.
+//   tab: [n_steps][5] doubles per step t: (ux, uy, z, lr_t, h0_t) -- h0_t replaces h[0] (1 - beta1 or the momentum: CyclicLR cycles
+//        it) when >= 0; c.x = (float)(lr * ux), c.y = (float)(lr * uy) for the kinds whose
+//        c.x / c.y are proportional to the learning rate (all; sgd's first-step flag travels in uy with ux-only scaling),
+//        c.z = (float)z, c.w = (float)(1 - lr * wd) for adamw; lr = lr_clip[clip] when lr_clip != null (ReduceLROnPlateau
+//        state, per clip) else lr_t;
+//   the box comes from c0 and `ratio` (box_bounds), the best snapshot follows improved[clip] (multibit_embedder.py:116-122).
+__global__ __launch_bounds__(256) void opt_rows_kernel(int kind, float* __restrict__ coef, const float* __restrict__ grad,
+                                                       float* __restrict__ mom, float* __restrict__ vel,
+                                                       const float* __restrict__ c0, float ratio, float* __restrict__ best,
+                                                       const int* __restrict__ improved, const int* __restrict__ frame_off, int B,
+                                                       const double* __restrict__ tab, int tab_len, const int* __restrict__ step,
+                                                       const double* __restrict__ lr_clip, double wd, OptHyp H, int nband) {
+    const int row = blockIdx.x, f = threadIdx.x;
+    int lo_ = 0, hi_ = B;                               // clip of this row: frame_off[clip] <= row < frame_off[clip + 1]
+    while (hi_ - lo_ > 1) {
+        const int mid = (lo_ + hi_) >> 1;
+        if (frame_off[mid] <= row) lo_ = mid; else hi_ = mid;
+    }
+    const int clip = lo_;
+    if (f >= nband) return;
+    const int t = min(max(*step - 1, 0), tab_len - 1);  // the read-out kernel already advanced the counter
+    const double* e = tab + (size_t)t * 5;
+    const double lr = lr_clip ? lr_clip[clip] : e[3];
+    if (e[4] >= 0.0) H.h[0] = (float)e[4];
+    float4 c;
+    c.x = (float)(lr * e[0]);
+    c.y = kind == OPT_SGD ? (float)e[1] : (float)(lr * e[1]);
+    c.z = (float)e[2];
+    c.w = (float)(1.0 - lr * wd);
+    const size_t idx = (size_t)row * kFS + f;
+    float p = coef[idx], mo = mom[idx], ve = vel[idx], blo, bhi;
+    box_bounds(c0[idx], ratio, blo, bhi);
+    opt_clamp_update(kind, p, mo, ve, grad[idx], blo, bhi, c, H);
+    coef[idx] = p; mom[idx] = mo; vel[idx] = ve;
+    if (improved[clip]) best[idx] = p;
+}
+void launch_opt_rows(int kind, float* coef, const float* grad, float* mom, float* vel, const float* c0, float ratio, float* best,
+                     const int* improved, const int* frame_off, int B, int NF, const double* tab, int tab_len, const int* step,
+                     const double* lr_clip, double wd, const float* h8, int nband, hipStream_t st) {
+    OptHyp H;
+    for (int i = 0; i < 8; ++i) H.h[i] = h8[i];
+    hipLaunchKernelGGL(opt_rows_kernel, dim3(NF), dim3(256), 0, st, kind, coef, grad, mom, vel, c0, ratio, best, improved, frame_off,
+                       B, tab, tab_len, step, lr_clip, wd, H, nband);
+}
+
+// torch.optim.lr_scheduler.ReduceLROnPlateau(mode 'min', threshold_mode 'rel', cooldown 0), one state per clip, stepped with
+// the clip's loss AFTER the optimiser step like the reference's loop (embedding/multibit_embedder.py:112-113; schedulers.py:4):
+// python-float (double) arithmetic as torch's.  state: [B][3] doubles (best, num_bad_epochs, unused); lr_clip [B].
+__global__ __launch_bounds__(256) void plateau_kernel(const float* __restrict__ loss, double* __restrict__ state,
+                                                      double* __restrict__ lr_clip, int B, double factor, int patience,
+                                                      double threshold, double min_lr, double eps) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const double cur = (double)loss[b];
+    double best = state[3 * b], bad = state[3 * b + 1];
+    if (cur < best * (1.0 - threshold)) { best = cur; bad = 0.0; }
+    else bad += 1.0;
+    if (bad > (double)patience) {
+        const double old = lr_clip[b], nw = fmax(old * factor, min_lr);
+        if (old - nw > eps) lr_clip[b] = nw;
+        bad = 0.0;
+    }
+    state[3 * b] = best; state[3 * b + 1] = bad;
+}
+void launch_plateau(const float* loss, double* state, double* lr_clip, int B, double factor, int patience, double threshold,
+                    double min_lr, double eps, hipStream_t st) {
+    hipLaunchKernelGGL(plateau_kernel, dim3((B + 255) / 256), dim3(256), 0, st, loss, state, lr_clip, B, factor, patience, threshold,
+                       min_lr, eps);
+}
+
 // out[c][r] = in[r][c] for in [R][C] row-major (32 x 32 tiles through LDS, both sides coalesced).  Used to turn the
 // weight-gradient contraction over rows, dW = dZ^T X, into the K-contiguous NT form of the GEMM kernels.
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C) {

@@ -18,7 +18,7 @@ from ..utils.audio import ISTFT, STFT, STFTAssembler, STFTDecomposer, WaveformNo
 from ..utils.logger import logger
 from .. import runtime as rt
 from .losses import get_loss_fn
-from .optimizers import get_optimizer
+from .optimizers import get_optimizer, is_card_default
 from .schedulers import get_scheduler
 
 
@@ -40,7 +40,7 @@ class AWAREEmbedder(BaseEmbedder):
         self.scheduler_name, self.scheduler_params = scheduler_cfg["name"], scheduler_cfg.get("params", {}) or {}
         self.loss = get_loss_fn(loss)                     # ValueError on an unknown name, as the reference
         self._opt = get_optimizer(self.optimizer_name, None, **self.optimizer_params)
-        self._sched = get_scheduler(self.scheduler_name, num_iterations, **self.scheduler_params)
+        self._sched = get_scheduler(self.scheduler_name, self._opt, num_iterations, **self.scheduler_params)
         self.verbose = verbose
         self.use_graph = use_graph
         self.audio_preprocess_pipeline = [WaveformNormalizer(), STFT(frame_length, hop_length, window, win_length), STFTDecomposer()]
@@ -60,12 +60,21 @@ class AWAREEmbedder(BaseEmbedder):
     # ---- batched hot path ----------------------------------------------------------------------
     def start_session(self, batch: "rt.Batch", sample_rate: int) -> "rt.EmbedSession":
         plan = self._plan(sample_rate)
-        b1, b2 = self._opt["betas"]
-        return rt.EmbedSession(plan, self.detection_net.device_weights(plan), batch,
-                               num_iterations=self.num_iterations, tolerance_db=self.tolerance_db,
-                               loss=self.loss.name, lr=self._opt["lr"], beta1=b1, beta2=b2, eps=self._opt["eps"],
-                               momentum_decay=self._opt["momentum_decay"], use_graph=self.use_graph,
-                               l1_weight=getattr(self.loss, "l1_weight", 0.0))
+        common = dict(num_iterations=self.num_iterations, tolerance_db=self.tolerance_db, loss=self.loss.name,
+                      use_graph=self.use_graph, l1_weight=getattr(self.loss, "l1_weight", 0.0))
+        det = self.detection_net.device_weights(plan)
+        if is_card_default(self._opt) and self._sched["constant_lr"]:
+            # the model card's configuration (NAdam, a scheduler that cannot fire): fused in the adjoint kernel's epilogue
+            g = self._opt["group"]
+            return rt.EmbedSession(plan, det, batch, lr=g["lr"], beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"],
+                                   momentum_decay=g["momentum_decay"], **common)
+        # any other registry entry (embedding/optimizers.py:3-20, schedulers.py:3-16): per-step scalars from the host.  The
+        # scheduler object is consumed by building the table, so each session gets fresh ones
+        opt = get_optimizer(self.optimizer_name, None, **self.optimizer_params)
+        sched = get_scheduler(self.scheduler_name, opt, self.num_iterations, **self.scheduler_params)
+        sess = rt.EmbedSession(plan, det, batch, **common)
+        sess.set_optimizer(opt, sched)
+        return sess
 
     def embed_device(self, audio: torch.Tensor, batch: "rt.Batch", sample_rate: int, watermarks: torch.Tensor,
                      rescale: torch.Tensor | None = None, session: "rt.EmbedSession" = None):

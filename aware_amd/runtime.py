@@ -194,6 +194,35 @@ def waveform_normalize_bwd(x: "Ragged", grad_out: torch.Tensor) -> torch.Tensor:
     return gi
 
 
+class OptClamp:
+    """Any optimiser of the reference's registry (embedding/optimizers.py:3-20) as ONE kernel on the caller's tensors, followed by
+    torch.clamp(param, lo, hi): the generic form of NAdamClamp for the plug-in seam (aware_opt_clamp_step).  `scheduler`: a
+    table scheduler dict of embedding.schedulers.get_scheduler (or None)."""
+
+    def __init__(self, param: torch.Tensor, name: str, num_steps: int, scheduler_name: str | None = None, scheduler_params=None,
+                 **params):
+        from .embedding.optimizers import get_optimizer, step_table
+        from .embedding.schedulers import get_scheduler
+        self.lib = load_library()
+        self.param = param
+        self.opt = get_optimizer(name, None, **params)
+        sched = get_scheduler(scheduler_name, self.opt, num_steps, **(scheduler_params or {})) if scheduler_name else None
+        if sched is not None and sched["plateau"] is not None:
+            raise NotImplementedError("OptClamp: a firing ReduceLROnPlateau needs the per-clip state of an embed session")
+        self.table = step_table(self.opt, num_steps, sched["torch"] if sched else None)
+        self.s1 = torch.zeros_like(param)
+        self.s2 = torch.zeros_like(param)
+        self.t = 0
+
+    def step(self, grad: torch.Tensor, lo: torch.Tensor | None = None, hi: torch.Tensor | None = None):
+        from .embedding.optimizers import step_scalars
+        self.t += 1
+        c4, h8 = step_scalars(self.opt, self.table, self.t)
+        check(self.lib.aware_opt_clamp_step(self.opt["kind"], _ptr(self.param), _ptr(grad), _ptr(self.s1), _ptr(self.s2), _ptr(lo),
+                                            _ptr(hi), self.param.numel(), c4.ctypes.data_as(C.POINTER(C.c_float)),
+                                            h8.ctypes.data_as(C.POINTER(C.c_float)), _stream()), "aware_opt_clamp_step")
+
+
 class NAdamClamp:
     """torch.optim.NAdam (single tensor, defaults of cards/config.yaml) followed by torch.clamp(param, lo, hi), as ONE
     kernel on the caller's tensors (aware_nadam_clamp_step): the optimiser step of the reference's loop
@@ -343,6 +372,25 @@ class EmbedSession:
         except Exception:
             pass
 
+    def set_optimizer(self, opt: dict, sched: dict):
+        """Any optimiser / scheduler of the reference's registries (embedding.optimizers.get_optimizer /
+        embedding.schedulers.get_scheduler dicts) instead of the model card's fused NAdam (aware_embed_set_optimizer)."""
+        from .embedding.optimizers import hyper_parameters, step_table
+        tab = np.ascontiguousarray(step_table(opt, self.cfg.num_iterations, sched["torch"]), dtype=np.float64)
+        hyp, wd = hyper_parameters(opt)
+        oc = _lib.OptimizerConfig()
+        oc.kind = opt["kind"]
+        oc.hyp = (C.c_float * 8)(*hyp)
+        oc.weight_decay = wd
+        oc.table = tab.ctypes.data_as(C.POINTER(C.c_double))
+        pl = sched["plateau"]
+        oc.plateau = int(pl is not None)
+        if pl:
+            oc.patience, oc.factor, oc.threshold, oc.min_lr, oc.eps = pl["patience"], pl["factor"], pl["threshold"], pl["min_lr"], pl["eps"]
+        oc.lr0 = float(tab[0, 3])
+        check(self.lib.aware_embed_set_optimizer(self.h, C.byref(oc), _stream()), "aware_embed_set_optimizer")
+        self._opt_table = tab
+
     def begin(self, audio: torch.Tensor, target: torch.Tensor):
         self._audio, self._target = audio, target.contiguous().float()
         check(self.lib.aware_embed_begin(self.h, _ptr(audio), _ptr(self._target), _stream()), "aware_embed_begin")
@@ -398,6 +446,13 @@ class EmbedSession:
     @property
     def step(self):
         return self._view(8, (1,), torch.int32)
+
+    def clip_learning_rates(self) -> np.ndarray:
+        """Per-clip learning rates of a session whose optimiser was set with set_optimizer (device state, float64; they only
+        differ from the table's rate under a firing ReduceLROnPlateau)."""
+        if not self.lib.aware_embed_buffer(self.h, 11):
+            raise AwareHipError("no optimiser was set with set_optimizer")
+        return self._view(11, (self.batch.B,), torch.float64).cpu().numpy()
 
 
 def gemm_nt(a: torch.Tensor, bt: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
@@ -671,3 +726,30 @@ def spectral_quantize(spec: torch.Tensor, step_db: float, floor_db: float) -> to
     check(lib.aware_spectral_quantize(_ptr(spec), spec.shape[0], float(step_db), float(floor_db), _stream()),
           "aware_spectral_quantize")
     return spec
+
+
+def spectral_quantize_bwd(spec_in: torch.Tensor, grad_out: torch.Tensor, step_db: float, floor_db: float) -> torch.Tensor:
+    """Backward of the surrogate (straight-through on the magnitude, exact through the phase); spec_in: the spectrum before
+    quantisation."""
+    lib = load_library()
+    gin = torch.empty_like(spec_in)
+    go = grad_out.contiguous()
+    check(lib.aware_spectral_quantize_bwd(_ptr(spec_in), _ptr(go), _ptr(gin), spec_in.shape[0], float(step_db), float(floor_db),
+                                          _stream()), "aware_spectral_quantize_bwd")
+    return gin
+
+
+class SpectralQuantizeSTE(torch.autograd.Function):
+    """The MP3-like surrogate as a differentiable torch op on a [frames, 520] complex64 spectrum (aware_spectral_quantize /
+    aware_spectral_quantize_bwd)."""
+
+    @staticmethod
+    def forward(ctx, spec, step_db, floor_db):
+        ctx.save_for_backward(spec)
+        ctx.step_db, ctx.floor_db = float(step_db), float(floor_db)
+        return spectral_quantize(spec.detach().clone(), step_db, floor_db)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (spec,) = ctx.saved_tensors
+        return spectral_quantize_bwd(spec, grad_out, ctx.step_db, ctx.floor_db), None, None

@@ -215,6 +215,38 @@ typedef struct aware_embed_config {
     float l1_weight;
 } aware_embed_config;
 
+/* ---- optimiser / scheduler registries (the reference's third seam: embedding/optimizers.py:3-20, schedulers.py:3-16) ------
+ * The model card's NAdam + never-firing ReduceLROnPlateau runs fused in the adjoint kernel's epilogue (aware_embed_config).
+ * Any other registered optimiser / schedule: the HOST computes the per-step scalars of torch's single-tensor update under
+ * the chosen learning-rate schedule, the device applies them in one element-wise launch per iteration (+ clamp, + best
+ * snapshot).  kind: AWARE_OPT_*.  table: HOST [num_iterations][5] doubles per step t = 1..: (ux, uy, z, lr_t, h0_t) with
+ * c.x = lr*ux, c.y = lr*uy (sgd: uy = 1 on the first step), c.z = z, h0_t >= 0 overrides hyp[0] (CyclicLR cycles beta1 /
+ * momentum); hyp: see csrc/dsp_args.hpp::opt_clamp_update.  plateau != 0: torch's ReduceLROnPlateau (mode min, rel
+ * threshold, cooldown 0) with one state PER CLIP, stepped with the clip's loss after each optimiser step; lr0 = initial rate.
+ * Call after aware_embed_create and before the first aware_embed_iterate. */
+#define AWARE_OPT_NADAM 0
+#define AWARE_OPT_ADAM 1
+#define AWARE_OPT_ADAMW 2
+#define AWARE_OPT_SGD 3
+#define AWARE_OPT_RMSPROP 4
+#define AWARE_OPT_ADAGRAD 5
+#define AWARE_OPT_ADAMAX 6
+#define AWARE_OPT_ADADELTA 7
+typedef struct aware_optimizer_config {
+    int kind;
+    float hyp[8];
+    double weight_decay;      /* adamw only (decoupled); the L2 form of the others travels in hyp[4] */
+    const double* table;
+    int plateau, patience;
+    double factor, threshold, min_lr, eps, lr0;
+} aware_optimizer_config;
+int aware_embed_set_optimizer(aware_embed* e, const aware_optimizer_config* cfg, void* stream);
+/* the same update on the caller's flat tensors, for the plug-in loop (generalises aware_nadam_clamp_step): coef4 = the
+ * step's (c.x, c.y, c.z, c.w) as float, hyp8 as above; state1 = exp_avg / momentum buffer / acc_delta, state2 = exp_avg_sq /
+ * square_avg / state_sum / exp_inf */
+int aware_opt_clamp_step(int kind, float* param, const float* grad, float* state1, float* state2, const float* lo,
+                         const float* hi, size_t n, const float* coef4, const float* hyp8, void* stream);
+
 size_t aware_embed_workspace_bytes(const aware_batch* batch, const aware_detector* det);
 int aware_embed_create(aware_embed** out, const aware_plan* plan, const aware_detector* det,
                        const aware_batch* batch, const aware_embed_config* cfg, void* workspace,
@@ -242,7 +274,8 @@ int aware_embed_profile(aware_embed* e, int n_iters, int max_entries, float* ms_
  * (service/embed.py:69,73): out[b] = rescale[b] * normalise(istft(...)).  rescale: dev f32 [B] or NULL. */
 int aware_embed_finish(aware_embed* e, const float* rescale, float* out, void* stream);
 /* device pointers to internal state for inspection: 0 loss[B], 1 best_loss[B], 2 pred[B][n_bits],
- * 3 coef [frames][256], 4 best coef, 5 lo, 6 hi, 7 phasor (complex64), 8 step counter (int32) */
+ * 3 coef [frames][256], 4 best coef, 5 lo, 6 hi, 7 phasor (complex64), 8 step counter (int32), 9 un-normalised synthesis,
+ * 10 band magnitudes of the last analysis, 11 per-clip learning rates (f64 [B]; NULL unless aware_embed_set_optimizer ran) */
 void* aware_embed_buffer(aware_embed* e, int which);
 
 /* ---- attacks (scripts/attacks.py) ------------------------------------------------------------------
@@ -288,6 +321,14 @@ int aware_gaussian_noise(const float* in, float* out, const int* off, const int*
  * step_db grid relative to the frame maximum and zeroed below floor_db; the phase is kept.
  * Used as  aware_stft -> aware_spectral_quantize -> aware_istft. */
 int aware_spectral_quantize(void* spec, int n_frames, float step_db, float floor_db, void* stream);
+/* Its backward, which makes the surrogate a DIFFERENTIABLE op (north_star: "differentiable MP3-like quantisation
+ * surrogates"; the reference's MP3Compression, scripts/attacks.py:73-148, shells out to ffmpeg and has no gradient):
+ * straight-through on the magnitude (dQ/d|X| := 1 on kept bins, 0 on bins dropped below the floor, frame maximum constant),
+ * exact through the phase.  spec_in: the spectrum BEFORE quantisation; grad_out = dL/dRe Y + i dL/dIm Y; grad_in likewise for
+ * X; all dev complex64 [n_frames][AWARE_FULL_STRIDE].  Specified by oracle/aware_oracle.py::mp3_surrogate_spectrum under torch
+ * autograd (parity unpinned: extension). */
+int aware_spectral_quantize_bwd(const void* spec_in, const void* grad_out, void* grad_in, int n_frames, float step_db,
+                                float floor_db, void* stream);
 
 /* EXTENSION (stand-in for the reference's rubberband-based TimeStretch / PitchShift, scripts/attacks.py:208-252; the
  * binary is absent, parity with it unpinned): phase vocoder on one-sided spectra [frames][AWARE_FULL_STRIDE] complex64.

@@ -281,7 +281,13 @@ class Embedder:
     """AWAREEmbedder.embed / _optimize -- embedding/multibit_embedder.py:70-197."""
 
     def __init__(self, num_iterations=NUM_ITERATIONS, tolerance_db=TOLERANCE_DB,
-                 loss="push_extremes", dtype=torch.float32, l1_weight=0.0):
+                 loss="push_extremes", dtype=torch.float32, l1_weight=0.0,
+                 optimizer=None, optimizer_params=None, scheduler=None, scheduler_params=None):
+        """optimizer / scheduler: names of the reference's registries (embedding/optimizers.py:3-20, schedulers.py:3-16) run
+        through torch.optim exactly as the reference's loop does (:85-86, :112-113); None = the model card's NAdam(lr 0.1)
+        with a constant rate, restated by hand below (nadam_step)."""
+        self.optimizer, self.optimizer_params = optimizer, dict(optimizer_params or {})
+        self.scheduler, self.scheduler_params = scheduler, dict(scheduler_params or {})
         self.det = Detector(dtype)
         self.l1_weight = l1_weight if loss == "push_extremes_l1" else 0.0
         self.num_iterations = num_iterations
@@ -326,6 +332,55 @@ class Embedder:
             # EXTENSION: imperceptibility as an L1 penalty on the coefficient change, per clip
             loss = loss + self.l1_weight * (coeffs - mag0[:, self.band]).abs().mean(dim=(-2, -1))
         return loss, pred
+
+    def embed_registry(self, audio, watermark, record=None):
+        """The loop with an optimiser / scheduler from the reference's registries, ONE clip (audio [1, n]) like the reference:
+        optimizer = registry[name]([coeffs], **params); scheduler = registry[name](optimizer, **params); per iteration
+        loss.backward(); optimizer.step(); scheduler.step(...); clamp; best tracking (:85-122).  ReduceLROnPlateau is stepped
+        with the loss as the reference does (:113).  The reference passes the loss to EVERY scheduler -- for the step-count
+        schedulers that lands in torch's deprecated `epoch` argument (last_epoch := loss, a usage error torch warns about);
+        here they are stepped without an argument, their documented per-iteration use.  record(it, loss, lr)."""
+        opt_reg = {"adam": torch.optim.Adam, "nadam": torch.optim.NAdam, "sgd": torch.optim.SGD, "rmsprop": torch.optim.RMSprop,
+                   "adagrad": torch.optim.Adagrad, "adadelta": torch.optim.Adadelta, "adamax": torch.optim.Adamax,
+                   "adamw": torch.optim.AdamW}
+        sch = torch.optim.lr_scheduler
+        sched_reg = {"reduce_lr_on_plateau": sch.ReduceLROnPlateau, "cosine_annealing": sch.CosineAnnealingLR,
+                     "cosine_annealing_warm_restarts": sch.CosineAnnealingWarmRestarts, "step": sch.StepLR,
+                     "multi_step": sch.MultiStepLR, "exponential": sch.ExponentialLR, "cyclic": sch.CyclicLR}
+        audio = torch.as_tensor(audio, dtype=self.dtype)
+        target = torch.as_tensor(watermark, dtype=self.dtype)
+        assert audio.shape[0] == 1
+        with torch.no_grad():
+            mag0, phase = self.analyse(audio)
+            c0 = mag0[:, self.band].clone()
+            lo, hi = self.bounds(c0)
+        c = c0.clone().requires_grad_(True)
+        optimizer = opt_reg[self.optimizer or "nadam"]([c], **(self.optimizer_params or {"lr": LR}))
+        scheduler = sched_reg[self.scheduler](optimizer, **self.scheduler_params) if self.scheduler else None
+        best_loss, best_c = float("inf"), c0.clone()
+        for it in range(self.num_iterations):
+            optimizer.zero_grad()
+            loss, pred = self.forward_loss(c, mag0, phase, target)
+            lr_used = float(optimizer.param_groups[0]["lr"])
+            loss.sum().backward()
+            optimizer.step()
+            if scheduler is not None:
+                if self.scheduler == "reduce_lr_on_plateau":
+                    scheduler.step(loss.detach()[0])
+                else:
+                    scheduler.step()
+            with torch.no_grad():
+                c.data = torch.clamp(c.data, lo, hi)
+                if float(loss) < best_loss:
+                    best_loss, best_c = float(loss), c.detach().clone()
+            if record is not None:
+                record(it, float(loss), lr_used)
+        with torch.no_grad():
+            mag = mag0.clone()
+            mag[:, self.band] = best_c
+            y = istft(mag * torch.exp(1j * phase))
+            y = y / torch.amax(torch.abs(y) + 1e-8, dim=-1, keepdim=True)
+        return y, best_loss
 
     def embed(self, audio, watermark, record=None):
         """embed (:141-197).  audio [B, n] f32, watermark [B, 20] bipolar.
@@ -701,6 +756,24 @@ def mp3_surrogate_attack(audio, n_levels_db=1.5, floor_db=-60.0):
     mq = fmax * torch.pow(10.0, q / 20.0)
     mq = torch.where(db < floor_db, torch.zeros_like(mq), mq)
     return istft(mq * torch.exp(1j * ph)).numpy()
+
+
+def mp3_surrogate_spectrum(S, n_levels_db=1.5, floor_db=-60.0):
+    """EXTENSION x2 as a DIFFERENTIABLE op on a spectrum S [513, T] (complex): the quantiser of mp3_surrogate_attack with a
+    straight-through magnitude path -- d(quantised magnitude)/d|S| := 1 on kept bins, 0 on bins dropped below the floor, the
+    frame maximum a constant -- and the exact phase path.  Forward values equal mp3_surrogate_attack's spectrum; under torch
+    autograd this function IS the specification of aware_spectral_quantize_bwd."""
+    mag = torch.abs(S)
+    ph = torch.angle(S)
+    with torch.no_grad():
+        fmax = mag.amax(dim=0, keepdim=True).clamp_min(1e-12)
+        db = 20.0 * torch.log10(mag.clamp_min(1e-12) / fmax)
+        q = torch.round(db / n_levels_db) * n_levels_db
+        mq = fmax * torch.pow(10.0, q / 20.0)
+        keep = (~(db < floor_db)) & (mag > 0)
+        mq = torch.where(keep, mq, torch.zeros_like(mq))
+    ste = torch.where(keep, mag + (mq - mag).detach(), torch.zeros_like(mag))
+    return ste * torch.exp(1j * ph)
 
 
 def phase_vocoder(D, rate, hop=256, n_fft=1024):

@@ -123,14 +123,60 @@ def test_registries_raise_like_the_reference():
     assert get_loss_fn("ber").kernel_id == 5 and get_loss_fn("push_sigmoid").kernel_id == 4
     with pytest.raises(ValueError, match="not found"):
         get_optimizer("nope")
-    with pytest.raises(NotImplementedError):
-        get_optimizer("adam")
-    assert get_optimizer("nadam", lr=0.1)["lr"] == 0.1
+    for name in ("adam", "nadam", "sgd", "rmsprop", "adagrad", "adadelta", "adamax", "adamw"):
+        assert get_optimizer(name)["name"] == name
+    for name in ("sparse_adam", "lbfgs"):            # cannot run in the reference's loop either
+        with pytest.raises(NotImplementedError):
+            get_optimizer(name)
+    with pytest.raises(TypeError):
+        get_optimizer("adam", no_such_argument=1)    # torch's own validation, as in the reference
+    nadam = get_optimizer("nadam", lr=0.1)
+    assert nadam["group"]["lr"] == 0.1
     with pytest.raises(ValueError, match="not found"):
-        get_scheduler("nope", 400)
-    assert get_scheduler("reduce_lr_on_plateau", 400, factor=0.9, patience=500)["constant_lr"]
+        get_scheduler("nope", nadam, 400)
+    assert get_scheduler("reduce_lr_on_plateau", nadam, 400, factor=0.9, patience=500)["constant_lr"]
+    fires = get_scheduler("reduce_lr_on_plateau", get_optimizer("nadam", lr=0.1), 400, factor=0.9, patience=10)
+    assert not fires["constant_lr"] and fires["plateau"]["patience"] == 10 and fires["plateau"]["factor"] == 0.9
     with pytest.raises(NotImplementedError):
-        get_scheduler("reduce_lr_on_plateau", 400, factor=0.9, patience=10)
+        get_scheduler("reduce_lr_on_plateau", get_optimizer("nadam", lr=0.1), 400, mode="max")
+    for name, kw in (("step", {"step_size": 7}), ("cosine_annealing", {"T_max": 50}), ("exponential", {"gamma": 0.99}),
+                     ("multi_step", {"milestones": [3, 9]}), ("cosine_annealing_warm_restarts", {"T_0": 10}),
+                     ("cyclic", {"base_lr": 0.01, "max_lr": 0.1, "step_size_up": 5})):
+        assert get_scheduler(name, get_optimizer("nadam", lr=0.1), 400, **kw)["torch"] is not None
+
+
+def test_step_tables_match_torch_semantics():
+    """The per-step scalars the device applies (optimizers.step_table): NAdam's against the oracle's restatement of
+    torch/optim/nadam.py (nadam_schedule), learning-rate columns against the closed forms of StepLR / ExponentialLR /
+    CosineAnnealingLR, CyclicLR's cycled beta1."""
+    import math
+    from oracle import aware_oracle as O
+    from aware_amd.embedding.optimizers import get_optimizer, step_table, is_card_default
+    from aware_amd.embedding.schedulers import get_scheduler
+    n = 50
+    opt = get_optimizer("nadam", lr=0.1)
+    assert is_card_default(opt) and not is_card_default(get_optimizer("nadam", lr=0.1, weight_decay=0.01))
+    tab = step_table(opt, n)
+    cg, cm, bc2 = O.nadam_schedule(n)
+    np.testing.assert_allclose(0.1 * tab[:, 0], np.asarray(cg, dtype=np.float64), rtol=2e-7)
+    np.testing.assert_allclose(0.1 * tab[:, 1], np.asarray(cm, dtype=np.float64), rtol=2e-7)
+    np.testing.assert_allclose(tab[:, 2], np.asarray(bc2, dtype=np.float64), rtol=2e-7)
+    assert np.all(tab[:, 3] == 0.1)
+    opt = get_optimizer("adam", lr=0.05)
+    tab = step_table(opt, n, get_scheduler("step", opt, n, step_size=7, gamma=0.5)["torch"])
+    np.testing.assert_allclose(tab[:, 3], [0.05 * 0.5 ** (t // 7) for t in range(n)], rtol=1e-12)
+    np.testing.assert_allclose(tab[:, 0], [-1.0 / (1 - 0.9 ** t) for t in range(1, n + 1)], rtol=1e-12)
+    opt = get_optimizer("sgd", lr=0.2, momentum=0.8)
+    tab = step_table(opt, n, get_scheduler("exponential", opt, n, gamma=0.97)["torch"])
+    np.testing.assert_allclose(tab[:, 3], [0.2 * 0.97 ** t for t in range(n)], rtol=1e-12)
+    assert tab[0, 1] == 1.0 and not tab[1:, 1].any() and np.all(tab[:, 4] == 0.8)
+    opt = get_optimizer("rmsprop", lr=0.01)
+    tab = step_table(opt, n, get_scheduler("cosine_annealing", opt, n, T_max=20)["torch"])
+    np.testing.assert_allclose(tab[:21, 3], [0.01 * (1 + math.cos(math.pi * t / 20)) / 2 for t in range(21)], rtol=1e-9, atol=1e-18)
+    opt = get_optimizer("nadam", lr=0.1)
+    tab = step_table(opt, n, get_scheduler("cyclic", opt, n, base_lr=0.01, max_lr=0.1, step_size_up=5)["torch"])
+    assert abs(tab[0, 3] - 0.01) < 1e-15 and abs(tab[5, 3] - 0.1) < 1e-12          # the rate climbs from base_lr to max_lr
+    assert abs(tab[0, 4] - (1 - 0.9)) < 1e-12 and abs(tab[5, 4] - (1 - 0.8)) < 1e-12   # beta1 cycles 0.9 -> 0.8 (cycle_momentum)
     from aware_amd.attacks import make_attack, ATTACKS
     assert make_attack("PCMBitDepthConversion", pcm=8).name == "pcm_8"
     assert make_attack("DeleteSamples", percentage=0.1).name == "delete_0.1"
