@@ -389,13 +389,17 @@ extern "C" int aware_istft(const aware_plan* plan, const aware_batch* b, const v
 extern "C" int aware_stft_bwd(const aware_plan* plan, const aware_batch* b, const void* grad_spec, float* grad_audio,
                               void* stream) {
     if (!plan || !b || !grad_spec || !grad_audio) return AWARE_E_BADARG;
-    // the adjoint of the reflect padding is implemented for signals of exactly 256*(T-1) samples (what the
-    // reference's loop feeds its STFT: the iSTFT output, multibit_embedder.py:49-67)
-    for (int i = 0; i < b->B; ++i)
-        if (b->n[i] != b->out_len[i] || b->in_off[i] != b->out_off[i]) return AWARE_E_UNSUPPORTED;
+    // the staged synthesis kernel in adjoint mode: overlap-add of the windowed rfft adjoints, then the fold of the two reflect
+    // pads for a clip of any length n > 512 at the clip's offset in the caller's ragged array
+    if (b->synth_run > 0)
+        for (int i = 0; i < b->B; ++i) {
+            const int nb = b->T[i] - 1, ns = (nb + b->synth_run - 1) / b->synth_run;
+            if (ns > 1 && nb / ns < 3) return AWARE_E_UNSUPPORTED;          // (aware_batch_create never builds such a batch)
+        }
     SynthLaunch S;
     S.plan = plan->dev; S.frame_off = b->d_frame_off; S.B = b->B; S.max_frames = b->max_frames; S.run_blocks = b->synth_run; S.wg_tab = b->d_syn_wg; S.n_wg = b->n_syn_wg;
     S.full = grad_spec; S.out = grad_audio; S.adjoint = 1; S.pstride = b->pstride;
+    S.sig_off = b->d_in_off; S.sig_len = b->d_in_len;
     launch_synth(S, (hipStream_t)stream);
     LAUNCHCHK();
     return AWARE_OK;

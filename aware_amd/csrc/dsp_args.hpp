@@ -162,6 +162,10 @@ struct SynthArgs {
     int run_blocks;                   // hop blocks per run / workgroup segment (<= kSynthBlocks)
     const float* c0;                  // streaming SY_FWD, L1 term: original coefficients; per-run sums of |amp - c0| go to
     double* pl1;                      //   pl1[B][pstride] (null: no L1 term)
+    // staged SY_ADJ on a full spectrum, general form (backward of aware_stft for clips of ANY length n > 512): clip b's
+    // gradient goes to out + sig_off[b], sig_len[b] samples, the right reflect pad mirrors about sample n - 1
+    const int* sig_off;
+    const int* sig_len;
 };
 
 

@@ -423,6 +423,22 @@ __global__ __launch_bounds__(kThreads) void synth_kernel(SynthArgs a) {
             __syncthreads();
             if (tid == 0) a.pmax[(size_t)b * a.pstride + blockIdx.x] = umax64(umax64(red[0], red[1]), umax64(red[2], red[3]));
         }
+    } else if (a.sig_len) {
+        // backward of torch.stft(center=True) for a clip of ANY length n = 256 (T-1) + r, r < 256 (utils/audio/stft.py:27-28
+        // under autograd): the padded signal has n + 1024 samples, the frames cover padded positions [0, 256 (T-1) + 1024);
+        // the left pad (p < 512) mirrors about sample 0, the right pad (p >= n + 512) about sample n - 1.  The first / last
+        // segment of a clip holds its pad and every sample the pad folds onto (segments are >= 3 hop blocks long).
+        const int n = a.sig_len[b];
+        float* og = a.out + a.sig_off[b];
+        const int j1e = ((int)blockIdx.x == nseg - 1) ? n : j1;
+        const int pend = kHop * (T - 1) + kNfft;                 // end of the frames' cover
+        for (int j = j0 + tid; j < j1e; j += kThreads) {
+            float g = ola[kHalf + j - pbase];
+            if (j >= 1 && j <= kHalf) g += ola[kHalf - j - pbase];
+            const int p = 2 * (n - 1) - j + kHalf;                // the pad position that reflects onto sample j
+            if (j <= n - 2 && p >= n + kHalf && p < pend) g += ola[p - pbase];
+            og[j] = g;
+        }
     } else {
         // adjoint of reflect padding: fold the two 512-sample pads back, then the partial
         // dot product with the normalised forward signal for the normaliser's backward
@@ -544,6 +560,7 @@ void launch_synth(const SynthLaunch& L, hipStream_t st) {
     a.amp = L.amp; a.ph = (const cf*)L.ph; a.full = (const cf*)L.full;
     a.out = L.out; a.add = L.add; a.pmax = L.pmax; a.pstride = L.pstride;
     a.yraw = L.yraw; a.pmax_in = L.pmax_in; a.pcount = L.pcount; a.pdot = L.pdot;
+    a.sig_off = L.sig_off; a.sig_len = L.sig_len;
     int nblk = L.max_frames - 1;
     a.run_blocks = (L.run_blocks >= 1 && L.run_blocks <= kSynthBlocks) ? L.run_blocks : kSynthBlocks;
     int nx = (nblk + a.run_blocks - 1) / a.run_blocks;

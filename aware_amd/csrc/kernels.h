@@ -74,6 +74,8 @@ struct SynthLaunch {
     int run_blocks = kSynthBlocks;    // hop blocks per run (aware_batch::synth_run); the partial counts follow it
     const float* c0 = nullptr;        // stream, forward: per-run sums of |amp - c0| into pl1 (L1 term)
     double* pl1 = nullptr;
+    const int* sig_off = nullptr;     // staged adjoint on a full spectrum: general-length output (see SynthArgs)
+    const int* sig_len = nullptr;
 };
 void launch_absmax_partials(const float* sig, const int* sig_off, const int* sig_len, unsigned long long* pmax,
                             int pstride, int B, int max_len, hipStream_t st);

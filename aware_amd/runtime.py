@@ -137,13 +137,10 @@ def stft_band(plan: Plan, batch: Batch, audio: torch.Tensor, normalize=True):
 
 
 def stft_bwd(plan: Plan, batch: Batch, grad_spec: torch.Tensor) -> torch.Tensor:
-    """Backward of `stft` (normalize=False): grad_spec [total_frames, 520] complex64 -> grad_audio [total_out] f32.
-    Clips must be exactly 256*(T-1) samples long (the iSTFT outputs the reference's loop transforms)."""
-    out = torch.empty(batch.total_out, dtype=torch.float32, device=grad_spec.device)
-    rc = plan.lib.aware_stft_bwd(plan.h, batch.h, _ptr(grad_spec), _ptr(out), _stream())
-    if rc == -2:
-        raise NotImplementedError("stft backward needs clips of exactly hop*(T-1) samples")
-    check(rc, "aware_stft_bwd")
+    """Backward of `stft` (normalize=False): grad_spec [total_frames, 520] complex64 -> grad_audio f32 laid out like the
+    audio `stft` takes (clip b: lengths[b] samples at in_offsets[b]); any clip length > 512."""
+    out = torch.zeros(batch.total_in, dtype=torch.float32, device=grad_spec.device)
+    check(plan.lib.aware_stft_bwd(plan.h, batch.h, _ptr(grad_spec), _ptr(out), _stream()), "aware_stft_bwd")
     return out
 
 

@@ -147,8 +147,8 @@ class WaveformNormalizer(BaseAudioProcessor):
 
 
 class STFT(BaseAudioProcessor):
-    """torch.stft(center=True, window, return_complex=True) (stft.py:14-28); differentiable for inputs of hop*(T-1)
-    samples (the iSTFT outputs the reference's loop feeds it)."""
+    """torch.stft(center=True, window, return_complex=True) (stft.py:14-28); differentiable for every input it accepts
+    (more than n_fft/2 samples)."""
 
     def __init__(self, n_fft: int = 2048, hop_length: int = 512, window: str = "hann", win_length: int = 2048):
         if window not in ("hann", "hamming"):

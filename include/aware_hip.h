@@ -105,9 +105,9 @@ int aware_stft_band(const aware_plan* plan, const aware_batch* batch, const floa
  * interfaces/audio.py:6-9; what torch autograd derives for torch.stft / torch.istft inside
  * embedding/multibit_embedder.py:49-67).  Gradients of a real loss; complex gradients in torch's convention
  * (dL/dRe + i dL/dIm).
- * aware_stft_bwd: grad_spec dev complex64 [total frames][AWARE_FULL_STRIDE] -> grad_audio dev f32 (clip b at
- *   aware_batch_out_offset).  Implemented for clips of exactly 256*(T-1) samples, densely packed (the iSTFT output the
- *   reference's loop transforms); AWARE_E_UNSUPPORTED otherwise.
+ * aware_stft_bwd: grad_spec dev complex64 [total frames][AWARE_FULL_STRIDE] -> grad_audio dev f32, laid out like the audio
+ *   aware_stft takes (clip b: n_b samples at in_offsets[b]): any clip length n > 512, ragged batches (the reflect pads fold
+ *   about sample 0 and sample n - 1).
  * aware_istft_bwd: grad_audio dev f32 [total out] -> grad_spec dev complex64 [total frames][AWARE_FULL_STRIDE]. */
 int aware_stft_bwd(const aware_plan* plan, const aware_batch* batch, const void* grad_spec, float* grad_audio,
                    void* stream);

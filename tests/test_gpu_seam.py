@@ -25,6 +25,39 @@ def env():
     return rt, emb, det, O
 
 
+@pytest.mark.parametrize("lengths", [[48000], [513], [16000, 48000, 23456, 777, 160000], [256 * 40, 256 * 40 + 255, 256 * 41 - 1]])
+def test_stft_backward_any_length(env, lengths):
+    """aware_stft_bwd for every input aware_stft accepts: clips of any length > 512 in a ragged batch (the reference's
+    torch.stft(center=True) under autograd, utils/audio/stft.py:27-28), against torch autograd on the oracle's explicit
+    restatement (reflect pad, unfold, window, rfft) with a random complex cotangent."""
+    rt, emb, det, O = env
+    from aware_amd.utils.audio import default_plan
+    plan = default_plan()
+    g = torch.Generator().manual_seed(sum(lengths))
+    clips = [0.1 * torch.randn(n, generator=g) for n in lengths]
+    batch = rt.Batch(lengths)
+    G = torch.zeros((batch.total_frames, rt.FULL_STRIDE), dtype=torch.complex64)
+    G[:, :513] = torch.complex(torch.randn(batch.total_frames, 513, generator=g), torch.randn(batch.total_frames, 513, generator=g))
+    ga = rt.stft_bwd(plan, batch, G.cuda()).cpu()
+    assert ga.shape[0] == sum(lengths)
+    for i, c in enumerate(clips):
+        x = c.clone().requires_grad_(True)
+        S = O.stft(x[None])[0]                                                   # [513, T]
+        Gi = G[batch.frame_offsets[i]: batch.frame_offsets[i + 1], :513].T
+        (S.real * Gi.real + S.imag * Gi.imag).sum().backward()
+        mine = ga[batch.in_offsets[i]: batch.in_offsets[i] + lengths[i]]
+        rel = float((mine - x.grad).norm() / x.grad.norm())
+        print(f"clip {i} (n = {lengths[i]}, T = {batch.frames[i]}): rel L2 {rel:.2e}")
+        assert rel < 2e-6, (i, rel)
+    # and through the plug-in object (single clip), as a torch op
+    from aware_amd.utils.audio import STFT
+    xd = clips[0].cuda().requires_grad_(True)
+    S = STFT(1024, 256, "hann", 1024)(xd)
+    Gi = G[: batch.frames[0], :513].T.cuda()
+    (S.real * Gi.real + S.imag * Gi.imag).sum().backward()
+    assert float((xd.grad.cpu() - ga[: lengths[0]]).abs().max()) == 0.0
+
+
 def test_transform_backward_matches_autograd(env):
     """STFT / ISTFT / normaliser / decomposer / assembler: gradients through the C ABI vs torch autograd on the oracle's
     explicit restatement (reflect pad, unfold, rfft, overlap-add), random cotangents."""
