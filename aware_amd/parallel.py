@@ -13,6 +13,15 @@ import torch
 import torch.distributed as dist
 
 
+# AWARE_FORCE_COLLECTIVES=1: create the process group and run every collective even with ONE rank -- the way to execute the
+# RCCL code path (communicator set-up, device all-reduce of float64 / float32 buffers, barrier) on a single-GPU box
+_FORCE = os.environ.get("AWARE_FORCE_COLLECTIVES", "0") not in ("", "0")
+
+
+def _active():
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE)
+
+
 def init_distributed(cpu_only: bool = False):
     """(rank, world_size, local_rank) from the torchrun environment; initialises the process
     group when WORLD_SIZE > 1 (RCCL on GPUs; gloo when there is no GPU or `cpu_only`, which never touches HIP)."""
@@ -20,7 +29,7 @@ def init_distributed(cpu_only: bool = False):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     gpu = (not cpu_only) and torch.cuda.is_available()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _FORCE) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if gpu:
@@ -48,7 +57,7 @@ def shard_by_cost(costs, world: int):
 
 def reduce_metrics(sums: dict, maxes: dict, device=None):
     """All-reduce a handful of scalars: `sums` with SUM, `maxes` with MAX.  No-op for one rank."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _active():
         return dict(sums), dict(maxes)
     device = device or (torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else "cpu")
     ks, km = sorted(sums), sorted(maxes)
@@ -60,7 +69,7 @@ def reduce_metrics(sums: dict, maxes: dict, device=None):
 
 
 def barrier():
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.barrier()
 
 
@@ -70,7 +79,7 @@ def all_reduce_gradients(grads, average: bool = True):
     6.7 MB for the model card's detector, far below the point where bucketing would pay; on 8 MI355X a ring all-reduce of
     that size is latency / per-link bound (7 links x ~153 GB/s), one launch is the right granularity.  In place; no-op for
     one rank.  RCCL on GPUs ("nccl" backend), gloo on CPU tensors."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _active():
         return grads
     flat = torch.cat([g.reshape(-1) for g in grads])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)

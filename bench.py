@@ -11,6 +11,8 @@ BASELINE.json's configs:
     config3 (default): 256 x 3 s clips per GPU, full attack stack [resample 16k<->44.1k, lowpass, gaussian 20 dB,
                        pcm16] -- the largest single-GPU configuration, the one the metric is quoted on
     config2:           64 x 3 s clips per GPU, clean embed -> detect
+    config3_l1:        config3 with the EXTENSION objective push_extremes + 0.05 * mean|c - c0| ("BER + L1" in BASELINE's wording;
+                       the reference has no such loss: parity unpinned, specified by the oracle)
     config4:           config3's per-GPU batch on every rank (8 GPUs: 2048 clips); the same code path as config3
     config5:           256 x N clips of seeded 1..10 s with a seeded attack chain per clip drawn from {pcm, resample,
                        lowpass, bandstop, cut, noise}; clips are assigned to ranks by frame count (shard_by_cost)
@@ -34,7 +36,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: dense f32-input MFMA peak
 MFMA_BF16_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak
-WORKLOADS = ["config2", "config3", "config4", "config5", "stub"]
+WORKLOADS = ["config2", "config3", "config3_l1", "config4", "config5", "stub"]
 CONFIG5_KINDS = ["pcm", "resample", "lowpass", "bandstop", "cut", "noise"]
 
 
@@ -69,10 +71,30 @@ def spawn_ranks(n, argv):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    # poll: on the first rank that exits non-zero, end its siblings (they would otherwise sit in the rendezvous or in a
+    # collective until torch's timeout, holding their GPUs) and report the failure.  Fresh children only, never an exec.
     rc = 0
-    for p in procs:
-        p.wait()
-        rc = rc or p.returncode
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                log(f"rank process {p.pid} exited with {code}: stopping the other ranks")
+                for q in live:
+                    q.terminate()
+        if rc != 0 and live:
+            deadline = time.time() + 10
+            for q in live:
+                try:
+                    q.wait(timeout=max(0.1, deadline - time.time()))
+                except subprocess.TimeoutExpired:
+                    q.kill()
+            live = []
     return rc
 
 
@@ -145,52 +167,42 @@ def cpu_baseline(workload):
                       f"({t_det*1e3:.1f} ms); vectorised bounds (no 1.3 s/clip Python loop)"}
 
 
-def gemm_clock_envelope(rt, clips, tp):
-    """The dominant kernel on one shape (1024 -> 1024 conv block of this batch, plain epilogue), timed on random operands
-    and on all-zero operands: cycles per MFMA do not depend on the data, the clock the chip holds under MFMA load does
-    (MI355X_MICROARCH.md, DVFS give-back), so the ratio separates issue efficiency from the power envelope."""
-    import torch
-    rows = clips * 32 * ((tp + 31) // 32)
-    g = torch.Generator(device="cuda").manual_seed(7)
-    out = {}
-    for kind in ("random", "zeros"):
-        if kind == "zeros":
-            a, w = torch.zeros((rows, 1024), device="cuda"), torch.zeros((1024, 1024), device="cuda")
-        else:
-            a = torch.randn((rows, 1024), device="cuda", generator=g)
-            w = torch.randn((1024, 1024), device="cuda", generator=g) / 32
-        packed = rt.x3_pack(w)
-        for _ in range(3):
-            rt.gemm_clip(a, w, None, clips, tp, 0, mode=1, packed=packed)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            rt.gemm_clip(a, w, None, clips, tp, 0, mode=1, packed=packed)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 10
-        out[kind + "_TFLOPs"] = round(2.0 * rows * 1024 * 1024 / (ms * 1e-3) / 1e12, 1)
-    out["frac_of_peak_on_zeros"] = round(out["zeros_TFLOPs"] / (MFMA_BF16_PEAK_TF / 6.0), 3)
-    out["note"] = ("same binary, same shape, f32-equivalent TFLOP/s on random and on all-zero operands: the gap is the clock the "
-                   "chip holds on random bf16 data, not issue slots (DESIGN.md section 4, profiles/r02_gemm_power_probe.txt)")
-    return out
+def kernel_source_hash():
+    """Hash of the kernel sources the library is built from: a stored counter profile is only quoted when it was taken on
+    the same kernels."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "aware_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".hpp", ".h")):
+            with open(os.path.join(csrc, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
 
 
-def pmc_traffic_per_launch(per_gpu):
+def pmc_traffic_per_launch(per_gpu, kernel_substr):
     """Mean HBM bytes per launch of the dominant kernel from the PMC passes stored under profiles/ (same command, same
-    batch; separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs -- bench.py cannot collect counters itself).
-    Returns (bytes, source) or (None, None) when no stored pass matches this batch size."""
+    batch; separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs -- bench.py cannot collect counters itself).  The CSV's
+    first comment line carries the hash of the kernel sources it was measured on: a profile of other kernels is NOT quoted
+    (traffic = null).  Returns (bytes, source) or (None, reason)."""
     import csv
     import glob
+    cur = kernel_source_hash()
+    reason = "no stored counter profile for this batch"
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_pmc.csv")), reverse=True):
         with open(path) as f:
-            rows = [r for r in csv.reader(l for l in f if not l.startswith("#"))][1:]
-        sel = [float(r[3]) + float(r[4]) for r in rows if int(r[0]) == per_gpu and "gemm_clip_x3_kernel<3," in r[1]]
+            lines = f.readlines()
+        tag = next((l.split("kernel_source_hash=")[1].split()[0] for l in lines if l.startswith("#") and "kernel_source_hash=" in l), None)
+        rel = os.path.relpath(path, ROOT)
+        if tag != cur:
+            reason = f"stored profile {rel} was taken on other kernel sources ({tag} != {cur}): not quoted"
+            continue
+        rows = [r for r in csv.reader(l for l in lines if not l.startswith("#"))][1:]
+        sel = [float(r[3]) + float(r[4]) for r in rows if int(r[0]) == per_gpu and kernel_substr in r[1]]
         if len(sel) == 5:
-            rel = os.path.relpath(path, ROOT)
-            return sum(sel) / len(sel) * 1048576.0, (f"stored profile {rel} of this workload (rocprofv3 --pmc FETCH_SIZE / "
-                                                     "WRITE_SIZE passes, gfx950 fetch x2 correction); not re-measured in this run")
-    return None, None
+            return sum(sel) / len(sel) * 1048576.0, (f"stored profile {rel} of this workload on these kernel sources (rocprofv3 --pmc "
+                                                     "FETCH_SIZE / WRITE_SIZE passes, gfx950 fetch x2 correction); not re-measured in this run")
+    return None, reason
 
 
 def run_stub(args, rank, world):
@@ -203,8 +215,8 @@ def run_stub(args, rank, world):
     parallel.barrier()
     wall = time.perf_counter() - t0
     sums, maxes = parallel.reduce_metrics({"seconds": 3.0 * args.steps, "ranks": 1}, {"wall": wall}, device="cpu")
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps({"metric": "stub", "value": sums["seconds"] / maxes["wall"], "unit": "waveform-seconds/sec",
@@ -254,6 +266,9 @@ def main():
     per_gpu = args.clips_per_gpu or (64 if wl == "config2" else 256)
     attacks = [] if wl == "config2" else config3_attack_stack()
     embedder, detector = load()
+    if wl == "config3_l1":
+        from aware_amd.embedding.losses import get_loss_fn
+        embedder.loss = get_loss_fn("push_extremes_l1", l1_weight=0.05)
     embedder.use_graph = not args.no_graph
     run_kw = {"input_rate": 44100}
     if wl == "config5":
@@ -278,8 +293,11 @@ def main():
             desc = "config2: %d x %.0f s clips/GPU @44.1 kHz -> 16 kHz, clean embed(400 it) -> detect" % (per_gpu, args.seconds)
         else:
             desc = ("%s: %d x %.0f s clips/GPU @44.1 kHz -> 16 kHz, embed(400 it) -> [resample 16k<->44.1k, lowpass, "
-                    "gaussian 20 dB, pcm16] -> detect" % (wl if wl == "config4" or world == 1 else "config4 (config3 per GPU)",
+                    "gaussian 20 dB, pcm16] -> detect" % (wl if wl != "config3" or world == 1 else "config4 (config3 per GPU)",
                                                           per_gpu, args.seconds))
+            if wl == "config3_l1":
+                desc += ("; objective push_extremes + 0.05 * mean|c - c0| (EXTENSION for BASELINE's 'BER + L1' -- the reference has no "
+                         "such loss: parity unpinned, specified by oracle/aware_oracle.py)")
     pipe.prepare(n16, input_rate=44100)                              # set-up (tables, tile choice, graphs), not a step
     log(f"rank {rank}/{world}: {len(n16)} clips ({sum(audio.lengths) / 44100.0:.0f} waveform-s) resident on {dev}; warm-up x{args.warmup}")
     for _ in range(args.warmup):
@@ -327,19 +345,30 @@ def main():
         all_ms = sum(breakdown[k][0] for k in gemm_kinds)
         all_n = sum(breakdown[k][1] for k in gemm_kinds)
         flops_iter = sum(detector_flops_per_clip_iter(t) for t in batch.frames)
-        peak = MFMA_BF16_PEAK_TF / 6.0
-        peak_note = ("f32-equivalent peak of the bf16x3 kernel: dense bf16 MFMA peak (2.5 PFLOP/s) / 6 bf16 partial products "
-                     "per f32 multiply-add")
+        uniform = len(set(batch.frames)) == 1 and batch.frames[0] // 2 <= 128
+        on_h2 = uniform and len(batch.frames) >= 32 and "gemm_x3_fwd" in breakdown   # capi.hip: kH2MinGrid, clip_tile_groups
+        if on_h2:
+            peak = MFMA_BF16_PEAK_TF / 3.0
+            peak_note = ("f32-equivalent peak of the f16 two-term kernel (gemm_h2.hip): dense f16 MFMA peak (2.5 PFLOP/s, the bf16 "
+                         "figure) / 3 partial products per f32 multiply-add")
+        else:
+            peak = MFMA_BF16_PEAK_TF / 6.0
+            peak_note = ("f32-equivalent peak of the bf16 three-term kernel (gemm_x3.hip): dense bf16 MFMA peak (2.5 PFLOP/s) / 6 "
+                         "partial products per f32 multiply-add")
         if "gemm_x3_fwd" in breakdown:
-            # dominant kernel: the clip-aligned conv block on the bf16 matrix pipe (gemm_x3.hip), 5 launches per
+            # dominant kernel: the conv block / data-gradient GEMM with fused InstanceNorm + LeakyReLU epilogues, 5 launches per
             # iteration: conv0..2 forward (K = 128, 512, 1024) and the data gradients of conv2, conv1 (K = 1024);
-            # (the skinny last conv and its data gradient live in the forward epilogue and in readout_x3_kernel)
+            # (the skinny last conv and its data gradient live in the forward epilogue and in the read-out kernels)
             fl = 2.0 * rows * (ch[0] * ch[1] + ch[1] * ch[2] + ch[2] * ch[3]) + 2.0 * rows * (ch[3] * ch[2] + ch[2] * ch[1])
             ms = breakdown["gemm_x3_fwd"][0] + breakdown["gemm_x3_bwd"][0]
             nl = breakdown["gemm_x3_fwd"][1] + breakdown["gemm_x3_bwd"][1]
-            name = "aware::gemm_clip_x3_kernel<RG,EPI,8> (forward EPI=1 x2 and EPI=3 x1, backward EPI=2 x2 per iteration)"
-            per_kernel = {"gemm_clip_x3_kernel<.,1|3,8>": round(breakdown["gemm_x3_fwd"][0] * 1e3 / breakdown["gemm_x3_fwd"][1], 2),
-                          "gemm_clip_x3_kernel<.,2,8>": round(breakdown["gemm_x3_bwd"][0] * 1e3 / breakdown["gemm_x3_bwd"][1], 2)}
+            kname = "gemm_clip_h2_kernel" if on_h2 else ("gemm_clip_x3_kernel / gemm_clip_x3_small_kernel" if uniform else "gemm_ragged_x3_kernel")
+            name = f"aware::{kname} (forward epilogue x3, backward epilogue x2 per iteration)"
+            if not uniform:
+                # the last conv's data gradient of a ragged batch is one more launch of this kind (readout_grad_ragged_x3_kernel)
+                fl += 2.0 * rows * ch[4] * ch[3]
+            per_kernel = {kname + " forward": round(breakdown["gemm_x3_fwd"][0] * 1e3 / breakdown["gemm_x3_fwd"][1], 2),
+                          kname + " backward": round(breakdown["gemm_x3_bwd"][0] * 1e3 / breakdown["gemm_x3_bwd"][1], 2)}
         else:
             fl, ms, nl = flops_iter, all_ms, all_n
             name = ("aware::gemm_clip_x3_kernel<1,0,8> on 32-row blocks (+ gemm_nt_kernel for shapes it does not serve): "
@@ -354,6 +383,8 @@ def main():
                 "frac_of_f32_mfma_peak": round(achieved / MFMA_F32_PEAK_TF, 4),
                 "traffic_unit": "bytes/launch", "traffic_source": None,
                 "avg_launch_us": round(ms * 1e3 / nl, 2), "launches_timed": nl,
+                "timing": "HIP events on the launch stream around every launch of 3 eager iterations (includes the eager "
+                          "inter-kernel gap that graph replay does not have); profiles/ holds the kernel trace of the same command",
                 "algorithmic_flops_per_launch": fl * n_it / nl, "avg_launch_us_by_kernel": per_kernel,
                 "all_detector_gemms": {"achieved": round(flops_iter * n_it / (all_ms * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
                                        "launches_per_iteration": all_n // n_it,
@@ -362,18 +393,17 @@ def main():
                             "unit": "GB/s", "frac": round(dsp_bytes / (dsp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                             "avg_launch_us": round(dsp_ms * 1e3 / (4 * n_it), 2),
                             "algorithmic_bytes_per_iteration": dsp_bytes // n_it}}
-        if "gemm_x3_fwd" in breakdown and len(set(batch.frames)) == 1:
-            tb, src = pmc_traffic_per_launch(len(batch.frames))
-            if tb is not None:
-                roof["traffic"], roof["traffic_source"] = round(tb), src
-            # operands of the five launches: A rows (f32) + output rows (f32) + packed weights (3 x bf16), and the
+        if "gemm_x3_fwd" in breakdown and uniform:
+            tb, src = pmc_traffic_per_launch(len(batch.frames), "gemm_clip_h2_kernel<3," if on_h2 else "gemm_clip_x3_kernel<3,")
+            roof["traffic"], roof["traffic_source"] = (round(tb) if tb is not None else None), src
+            # operands of the five launches: A rows (f32) + output rows (f32) + packed weights (2 x f16 or 3 x bf16), and the
             # forward activation re-read by the two backward epilogues
             pairs = [(ch[0], ch[1]), (ch[1], ch[2]), (ch[2], ch[3]), (ch[3], ch[2]), (ch[2], ch[1])]
-            alg = sum(4.0 * rows * (k + n) + 6.0 * k * n for k, n in pairs) + 4.0 * rows * (ch[2] + ch[1])
+            wb = 4.0 if on_h2 else 6.0
+            alg = sum(4.0 * rows * (k + n) + wb * k * n for k, n in pairs) + 4.0 * rows * (ch[2] + ch[1])
             roof["algorithmic_bytes_per_launch"] = round(alg / 5)
-            roof["clock_envelope"] = gemm_clock_envelope(rt, len(batch.frames), batch.frames[0] // 2)
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
         parallel.barrier()
         dist.destroy_process_group()
     if rank != 0:
@@ -384,8 +414,10 @@ def main():
         "value": round(value, 2), "unit": "waveform-seconds/sec", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(maxes["wall"] / args.steps * 1e3, 2), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 (detector GEMMs on the bf16 MFMA pipe with every f32 operand split exactly into 3 bf16 terms, 6 partial "
-                 "products, f32 accumulate: f32-equivalent)",
+        "dtype": "f32 (conv-block GEMMs on the 16-bit MFMA pipe with f32 accumulation and every f32 operand carried by a multi-term "
+                 "split: two binary16 terms after a power-of-two scaling, representation error <= half an f32 ulp, 3 partial "
+                 "products -- gemm_h2.hip; small grids / ragged batches / mel / read-out: three bf16 terms, exact, 6 products -- "
+                 "gemm_x3.hip.  Error against fp64 at or below the f32-input MFMA kernel's on every tested shape)",
         "data": "synthetic",
         "config": {"workload": desc, "clips_per_gpu": len(n16), "clip_seconds": clip_seconds,
                    "iterations": embedder.num_iterations,
@@ -394,6 +426,8 @@ def main():
         "ber_percent_clean": round(100.0 * sums["clean_bit_errors"] / sums["bits"], 4),
         "roofline": roof,
         "kernel_ms_per_iteration": {k: round(v[0] / 3, 4) for k, v in breakdown.items()},
+        "kernel_ms_per_iteration_note": "eager launches, HIP-event timed (each figure includes the 2-5 us eager inter-kernel gap; "
+                                        "their sum therefore exceeds ms_per_step / iterations, which runs from hipGraphs)",
     }
     if world == 1 and not args.no_cpu_baseline:
         log("timing the CPU oracle on a bounded sample (about 10-30 s)")
