@@ -592,6 +592,7 @@ struct DetBufs {
     float* pred;      // [B][nbits]
     float* zpart;     // split-K partial slabs of the last conv [kTailSplit][NP][C_last]
     int tail;         // 1: the last conv was left as partials for the fused tail kernel
+    int zslabs;       // partial slabs the forward epilogue left in zpart (fused read-out)
     // per-clip partial maxima [B][64] for the f16 two-term GEMM's scales: of x0 (index 0), of act[l] (index l + 1), and of
     // the two gradient ping-pong buffers (gmax)
     float* amax[9];
@@ -693,6 +694,7 @@ static int det_forward(const aware_detector* d, const aware_batch* b, const floa
                                     nwm, b->uniform_tp, co, ci, 1, o.rstd[l], nullptr, st, emit ? d->lastpk : nullptr,
                                     emit ? o.zpart : nullptr, d->ch[d->n_layers]);
                 cur_max = next_h2;
+                if (emit) o.zslabs = co / gemm_clip_h2_slab_width(nwm, co, b->B);
                 LAUNCHCHK(); PROF(K_GEMM_X3_FWD);
                 x = o.act[l];
                 continue;
@@ -700,6 +702,7 @@ static int det_forward(const aware_detector* d, const aware_batch* b, const floa
             cur_max = false;
             if (pipe != 1 && d->wpk[l] && gemm_clip_x3_supported(nwm, co, ci, ci)) {
                 const bool emit = skip_last && l == d->n_layers - 2;   // + split-K partials of the last conv
+                if (emit) o.zslabs = co / 128;
                 launch_gemm_clip_x3(x, ci, d->wpk[l], d->bias[l], o.act[l], co, b->B, nwm, b->uniform_tp, co, ci, 1, o.rstd[l],
                                     nullptr, st, emit ? d->lastpk : nullptr, emit ? o.zpart : nullptr, d->ch[d->n_layers]);
                 LAUNCHCHK(); PROF(K_GEMM_X3_FWD);
@@ -823,7 +826,7 @@ static int det_forward_backward(const aware_detector* d, const aware_batch* b, c
                gemm_clip_h2_supported(nwm, d->ch[l], d->ch[l + 1], d->ch[l + 1]);
     };
     if (fused_readout) {
-        launch_readout_x3(db.act[nl - 2], d->ch[nl - 1], db.zpart, d->ch[nl - 1] / 128, d->bias[nl - 1], d->lastTpk,
+        launch_readout_x3(db.act[nl - 2], d->ch[nl - 1], db.zpart, db.zslabs, d->bias[nl - 1], d->lastTpk,
                           db.rstd[nl - 2], G.target, db.pred, G.loss, G.best_loss, G.improved, G.step, dA, b->B,
                           nwm, b->uniform_tp, d->ch[nl], d->nbits, G.loss_kind, st, G.loss_add, dB,
                           h2_bwd(nl - 2) ? gA : nullptr);

@@ -127,19 +127,23 @@ __device__ __forceinline__ void h2_split_pair(float x, float y, float s, unsigne
 // acc[m] += (A[bm + 16 m .. +16)[0..K) * 2^sa) * (B 2^sb)^T for the wave's 16 columns bn + 16 wave ..; the caller unscales.
 // `lds`: 2 * 2 * 2 * 2RG KiB of staging memory (two K tiles of 64, two K32 steps, two planes); every wave of the workgroup
 // calls this with the same arguments; the caller provides a barrier between two calls that reuse `lds`.
-template <int RG>
+// NW waves per workgroup, NTW 16-column tiles per wave: the workgroup's slab is 16 NW NTW columns wide and the A tile it stages
+// is shared by all of them.
+template <int RG, int NW, int NTW>
 __device__ __forceinline__ void h2_tile_gemm(const float* __restrict__ A, int lda, const u32x4* __restrict__ Bpk, int K, int bm,
-                                             int bn, unsigned char* lds, f32x4 (&acc)[2 * RG], int row_limit, float ascale) {
-    constexpr int NT = 512;
+                                             int bn, unsigned char* lds, f32x4 (&acc)[2 * RG][NTW], int row_limit, float ascale) {
+    constexpr int NT = 64 * NW;
     constexpr int MT = 2 * RG;            // 16-row tiles per clip
     constexpr int MH = RG;                // ... per half (the unit of the A-fragment schedule)
     constexpr int FRAG = 1024;            // one 16-row x 32-k f16 fragment image, bytes
     constexpr int PLANE = MT * FRAG;
     constexpr int KSS = 2 * PLANE;        // one K32 step
     constexpr int BUF = 2 * KSS;          // one K tile (BK = 64)
-    // A staging: pass i covers rows 32 i .. 32 i + 31 of the K tile; thread -> (row tid >> 4, 4 floats at k = 4 (tid & 15)):
-    // one fully coalesced 16-byte load per lane (16 lanes = one 256-byte row segment) and one 8-byte LDS store per plane
-    constexpr int NPASS = RG;
+    // A staging: pass i covers rows RPP i .. RPP i + RPP - 1 of the K tile (RPP = threads / 16); thread -> (row tid >> 4, 4 floats
+    // at k = 4 (tid & 15)): one fully coalesced 16-byte load per lane (16 lanes = one 256-byte row segment) and one 8-byte
+    // LDS store per plane.  (1024 threads, 96 rows: the second pass has work for the first 8 waves only.)
+    constexpr int RPP = NT / 16;
+    constexpr int NPASS = (32 * RG + RPP - 1) / RPP;
 
     bm = __builtin_amdgcn_readfirstlane(bm);
     bn = __builtin_amdgcn_readfirstlane(bn);
@@ -152,17 +156,20 @@ __device__ __forceinline__ void h2_tile_gemm(const float* __restrict__ A, int ld
 
     const int KS2 = K >> 5;
     const int nkt = K >> 6;
-    const u32x4* bp = Bpk + ((size_t)((bn >> 4) + wave) * KS2) * 128;                // uniform; + lane per thread
+    const u32x4* bp = Bpk + ((size_t)((bn >> 4) + wave * NTW) * KS2) * 128;          // uniform; + lane per thread
     const float* ap = A + (size_t)bm * lda;                                          // uniform
     unsigned roff[NPASS];
 #pragma unroll
-    for (int i = 0; i < NPASS; ++i) roff[i] = (unsigned)(min(srow + 32 * i, row_limit - 1) * lda + k4 * 4);
+    for (int i = 0; i < NPASS; ++i) roff[i] = (unsigned)(min(srow + RPP * i, row_limit - 1) * lda + k4 * 4);
+    auto pass_ok = [&](int i) { return (32 * RG) % RPP == 0 || srow + RPP * i < 32 * RG; };      // wave-uniform
     // LDS slot of this thread's 4 k-values of row srow (+ 32 i: two fragment images further): the XOR of the row slot with
     // the k chunk keeps the 16 lanes of a row on 16 distinct 8-byte slots of a 128-byte bank row
     const unsigned woff = (unsigned)((sc >> 2) * KSS + (srow >> 4) * FRAG + (sc & 3) * 256 + (((srow & 15) ^ sc) * 16) + (k4 & 1) * 8);
 
 #pragma unroll
-    for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #ifndef H2_ABL
 #define H2_ABL 0          // timing-only ablations of the K loop (tools/h2_ablate.sh); results are invalid when non-zero
@@ -171,9 +178,10 @@ __device__ __forceinline__ void h2_tile_gemm(const float* __restrict__ A, int ld
     float4 ra[NPASS];
     auto gload_c = [&](int i, int kt) {
         if ((H2_ABL & 32) && in_loop) return;
-        ra[i] = *reinterpret_cast<const float4*>(ap + kt * 64 + roff[i]);
+        if (pass_ok(i)) ra[i] = *reinterpret_cast<const float4*>(ap + kt * 64 + roff[i]);
     };
     auto split_store_c = [&](int i, unsigned boff) {
+        if (!pass_ok(i)) return;
         uint2 qh, ql;
         if ((H2_ABL & 1) && in_loop) {
             qh = make_uint2(__float_as_uint(ra[i].x), __float_as_uint(ra[i].y));
@@ -182,7 +190,7 @@ __device__ __forceinline__ void h2_tile_gemm(const float* __restrict__ A, int ld
             h2_split_pair(ra[i].x, ra[i].y, ascale, qh.x, ql.x);
             h2_split_pair(ra[i].z, ra[i].w, ascale, qh.y, ql.y);
         }
-        unsigned char* d = lds + boff + woff + i * 2 * FRAG;
+        unsigned char* d = lds + boff + woff + i * (RPP / 16) * FRAG;
         if ((H2_ABL & 2) && in_loop) {
             asm volatile("" :: "v"(qh.x), "v"(qh.y), "v"(ql.x), "v"(ql.y));
         } else {
@@ -190,12 +198,18 @@ __device__ __forceinline__ void h2_tile_gemm(const float* __restrict__ A, int ld
             *reinterpret_cast<uint2*>(d + PLANE) = ql;
         }
     };
-    u32x4 bq[2][2];
+#ifndef H2_BDEPTH
+#define H2_BDEPTH 2        // B fragment sets in flight: the fragments of K32 step s are requested H2_BDEPTH - 1 steps ahead
+#endif
+    constexpr int BD = H2_BDEPTH;
+    u32x4 bq[BD][2][NTW];
     auto loadB = [&](int set, int ks2) {
         if ((H2_ABL & 8) && in_loop) return;
         ks2 = ks2 < KS2 ? ks2 : KS2 - 1;
 #pragma unroll
-        for (int p = 0; p < 2; ++p) bq[set][p] = (bp + ((size_t)ks2 * 2 + p) * 64)[(unsigned)lane];
+        for (int n = 0; n < NTW; ++n)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) bq[set][p][n] = (bp + (((size_t)n * KS2 + ks2) * 2 + p) * 64)[(unsigned)lane];
     };
     auto lds_barrier = [&]() {
         if ((H2_ABL & 16) && in_loop) return;
@@ -216,12 +230,15 @@ __device__ __forceinline__ void h2_tile_gemm(const float* __restrict__ A, int ld
     };
 #define H2_MFMA(a_, b_, hf_)                                                                                                   \
     _Pragma("unroll") for (int m = 0; m < MH; ++m)                                                                             \
-        acc[(hf_) * MH + m] = __builtin_amdgcn_mfma_f32_16x16x32_f16((a_)[m], __builtin_bit_cast(f16x8, (b_)), acc[(hf_) * MH + m], 0, 0, 0)
+        _Pragma("unroll") for (int n = 0; n < NTW; ++n)                                                                        \
+            acc[(hf_) * MH + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16((a_)[m], __builtin_bit_cast(f16x8, (b_)[n]),       \
+                                                                            acc[(hf_) * MH + m][n], 0, 0, 0)
 #define H2_PIN(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) gload_c(i, 0);
-    loadB(0, 0);
+#pragma unroll
+    for (int d = 0; d < BD - 1; ++d) loadB(d, d);
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) split_store_c(i, 0);
 #pragma unroll
@@ -231,24 +248,32 @@ __device__ __forceinline__ void h2_tile_gemm(const float* __restrict__ A, int ld
     read_l(rb[0]);
     if (H2_ABL) {            // (ablations: the second h set and the second B set are never refilled -- give them values)
         read_h(1, rb[0]);
-        bq[1][0] = bq[0][0]; bq[1][1] = bq[0][1];
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) { bq[1][0][n] = bq[0][0][n]; bq[1][1][n] = bq[0][1][n]; }
     }
     in_loop = true;
-    for (int kt = 0; kt < nkt; ++kt) {
+    // (the loop body covers BD K tiles when BD = 3 so that the B set of a K32 step is a compile-time index)
+    constexpr int KTU = (BD == 3) ? 3 : 1;
+    for (int kt0 = 0; kt0 < nkt; kt0 += KTU) {
+#pragma unroll
+      for (int ku = 0; ku < KTU; ++ku) {
+        const int kt = kt0 + ku;
+        if (KTU > 1 && kt >= nkt) break;
         const unsigned cur = (kt & 1) * BUF, nxt = BUF - cur;
         const int ktn = kt + 2 < nkt ? kt + 2 : nkt - 1;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {                 // quarter = (K32 step q>>1, row half q&1)
             const int t = q >> 1, hf = q & 1;
-            if (hf == 0) loadB((t + 1) & 1, kt * 2 + t + 1);          // B fragments one K32 step ahead
+            const int bs = (BD == 3) ? (2 * ku + t) % 3 : t;          // B set of this K32 step (step index mod BD)
+            if (hf == 0) loadB((bs + BD - 1) % BD, kt * 2 + t + BD - 1);   // B fragments BD - 1 K32 steps ahead
             if (q < NPASS) {
                 split_store_c(q, nxt);
                 gload_c(q, ktn);
             }
             const unsigned noff = q < 3 ? cur + rb[(q + 1) >> 1] + ((q + 1) & 1) * MH * FRAG : nxt + rb[0];
             if (q < 3) { read_h((q + 1) & 1, noff); H2_PIN(0x100, MH); }
-            H2_MFMA(al, bq[t][0], hf);                // l_a * h_b
-            H2_PIN(0x008, MH);
+            H2_MFMA(al, bq[bs][0], hf);               // l_a * h_b
+            H2_PIN(0x008, MH * NTW);
             if (q == 3) {                             // tile kt+1 is complete; every wave has finished its reads of tile kt
                 lds_barrier();
                 read_h(0, noff);
@@ -256,10 +281,11 @@ __device__ __forceinline__ void h2_tile_gemm(const float* __restrict__ A, int ld
             }
             read_l(noff);
             H2_PIN(0x100, MH);
-            H2_MFMA(ah[q & 1], bq[t][1], hf);         // h_a * l_b
-            H2_MFMA(ah[q & 1], bq[t][0], hf);         // h_a * h_b
-            H2_PIN(0x008, 2 * MH);
+            H2_MFMA(ah[q & 1], bq[bs][1], hf);        // h_a * l_b
+            H2_MFMA(ah[q & 1], bq[bs][0], hf);        // h_a * h_b
+            H2_PIN(0x008, 2 * MH * NTW);
         }
+      }
     }
 #undef H2_PIN
 #undef H2_MFMA
@@ -268,8 +294,10 @@ __device__ __forceinline__ void h2_tile_gemm(const float* __restrict__ A, int ld
 // ---------------------------------------------------------------------------------------------------
 // the conv block / data-gradient kernel for uniform batches (epilogues as gemm_clip_x3_kernel)
 // ---------------------------------------------------------------------------------------------------
-template <int RG, int EPI>
-__global__ __launch_bounds__(512, RG <= 3 ? 4 : 2) void gemm_clip_h2_kernel(
+// NW x NTW: 8 x 1 = 128-column slabs, two workgroups per CU; 16 x 1 (and 8 x 2, not instantiated: measured slower) = 256-column
+// slabs (half the A staging per MFMA), one workgroup per CU
+template <int RG, int EPI, int NW, int NTW>
+__global__ __launch_bounds__(64 * NW, (NW == 16) ? 4 : (NTW == 1 && RG <= 3) ? 4 : 2) void gemm_clip_h2_kernel(
     const float* __restrict__ A, int lda, const u32x4* __restrict__ Bpk, const float* __restrict__ binv,
     const float* __restrict__ amax_in, float* __restrict__ amax_out, const float* __restrict__ bias, float* __restrict__ C, int ldc,
     int Tp, int N, int K, int tiles_n, int ntiles, float* __restrict__ rstd_io, const float* __restrict__ act,
@@ -278,14 +306,16 @@ __global__ __launch_bounds__(512, RG <= 3 ? 4 : 2) void gemm_clip_h2_kernel(
     constexpr int MH = RG;
     constexpr int FRAG = 1024;
     constexpr int BUF = 2 * 2 * MT * FRAG;
-    // (the FWD_LAST epilogue re-lays the output tile as f32 [32 RG][132] in the same memory, then parks 8 waves x MH x 3
+    constexpr int SLABW = 16 * NW * NTW;             // columns per workgroup
+    constexpr int TPITCH = SLABW + 4;                // row pitch (floats) of the output tile re-laid in LDS (FWD_LAST)
+    // (the FWD_LAST epilogue re-lays the output tile as f32 [32 RG][TPITCH] in the same memory, then parks NW x MH x 3
     //  partial tiles of 1 KiB there)
-    constexpr int LASTB = 32 * RG * 132 * 4 > 8 * MH * 3 * FRAG ? 32 * RG * 132 * 4 : 8 * MH * 3 * FRAG;
+    constexpr int LASTB = 32 * RG * TPITCH * 4 > NW * MH * 3 * FRAG ? 32 * RG * TPITCH * 4 : NW * MH * 3 * FRAG;
     constexpr int LDSB = (EPI == X3_FWD_LAST && LASTB > 2 * BUF) ? LASTB : 2 * BUF;
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDSB];
 
     // block -> (clip, column slab): blocks b and b + 8 share an XCD (observed round-robin placement; speed only).  An XCD takes
-    // a contiguous range of clips and walks it slab-group-major, `sg` slabs at a time whose packed weights (sg * 128 * K * 4
+    // a contiguous range of clips and walks it slab-group-major, `sg` slabs at a time whose packed weights (sg * SLABW * K * 4
     // bytes) fit its L2 beside the activation rows in flight (gemm_x3.hip has the measurements).
     int id = blockIdx.x;
     int clip, slab_;
@@ -293,7 +323,7 @@ __global__ __launch_bounds__(512, RG <= 3 ? 4 : 2) void gemm_clip_h2_kernel(
         const int x = id & 7, j = id >> 3, R = ntiles >> 3;
         const int nclip = R / tiles_n;
         if (nclip * tiles_n == R && nclip > 0) {
-            int sg = (int)(3355443u / (unsigned)(128 * K * 4));
+            int sg = (int)(3355443u / (unsigned)(SLABW * K * 4));
             sg = sg < 1 ? 1 : (sg > tiles_n ? tiles_n : sg);
             while (tiles_n % sg) --sg;
             const int per_group = nclip * sg;
@@ -310,7 +340,7 @@ __global__ __launch_bounds__(512, RG <= 3 ? 4 : 2) void gemm_clip_h2_kernel(
         slab_ = id % tiles_n;
     }
     const int bm = clip * 32 * RG;
-    const int bn = slab_ * 128;
+    const int bn = slab_ * SLABW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kg = lane >> 4;
 
@@ -320,148 +350,162 @@ __global__ __launch_bounds__(512, RG <= 3 ? 4 : 2) void gemm_clip_h2_kernel(
     for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
     const float ascale = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(h2_scale_for(am))));
 
-    f32x4 acc[MT];
-    h2_tile_gemm<RG>(A, lda, Bpk, K, bm, bn, lds, acc, 32 * RG, ascale);
+    f32x4 acc[MT][NTW];
+    h2_tile_gemm<RG, NW, NTW>(A, lda, Bpk, K, bm, bn, lds, acc, 32 * RG, ascale);
 
-    // ---- epilogue: lane holds rows m*16 + 4*kg + e (e = 0..3) of column col ----
-    const int col = bn + wave * 16 + r16;
-    const float unscale = h2_pow2_inverse(ascale) * binv[col];
+    // ---- epilogue: lane holds rows m*16 + 4*kg + e (e = 0..3) of columns cb + 16 n ----
+    const int cb = bn + wave * (16 * NTW) + r16;
+    const float ainv = h2_pow2_inverse(ascale);
     const float invT = 1.0f / (float)Tp;
-    float omax = 0.f;                                   // max |output| of this wave's tile, for the next GEMM's scale
-    if (EPI == X3_PLAIN) {
-        const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+    for (int n = 0; n < NTW; ++n) {
+        const int col = cb + 16 * n;
+        const float unscale = ainv * binv[col];
+        float omax = 0.f;                               // max |output| of this wave's 16 columns, for the next GEMM's scale
+        if (EPI == X3_PLAIN) {
+            const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int row = m * 16 + 4 * kg + e;
-                const float o = row < Tp ? acc[m][e] * unscale + bv : 0.f;
-                omax = fmaxf(omax, fabsf(o));
-                C[(size_t)(bm + row) * ldc + col] = o;
-            }
-    } else if (EPI == X3_FWD || EPI == X3_FWD_LAST) {
-        const float bv = bias ? bias[col] : 0.f;
-        float s = 0.f;
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+                for (int e = 0; e < 4; ++e) {
+                    const int row = m * 16 + 4 * kg + e;
+                    const float o = row < Tp ? acc[m][n][e] * unscale + bv : 0.f;
+                    omax = fmaxf(omax, fabsf(o));
+                    C[(size_t)(bm + row) * ldc + col] = o;
+                }
+        } else if (EPI == X3_FWD || EPI == X3_FWD_LAST) {
+            const float bv = bias ? bias[col] : 0.f;
+            float s = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int row = m * 16 + 4 * kg + e;
-                acc[m][e] = acc[m][e] * unscale + bv;
-                if (row < Tp) s += acc[m][e];
-            }
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
-        const float mean = s * invT;
-        float qq = 0.f;
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+                for (int e = 0; e < 4; ++e) {
+                    const int row = m * 16 + 4 * kg + e;
+                    acc[m][n][e] = acc[m][n][e] * unscale + bv;
+                    if (row < Tp) s += acc[m][n][e];
+                }
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            const float mean = s * invT;
+            float qq = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int row = m * 16 + 4 * kg + e;
-                if (row < Tp) { const float d = acc[m][e] - mean; qq += d * d; }
-            }
-        qq += __shfl_xor(qq, 16);
-        qq += __shfl_xor(qq, 32);
-        const float rs = 1.0f / sqrtf(qq * invT + 1e-5f);      // biased variance, eps 1e-5 (InstanceNorm1d defaults)
-        if (kg == 0) rstd_io[(size_t)clip * N + col] = rs;
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+                for (int e = 0; e < 4; ++e) {
+                    const int row = m * 16 + 4 * kg + e;
+                    if (row < Tp) { const float d = acc[m][n][e] - mean; qq += d * d; }
+                }
+            qq += __shfl_xor(qq, 16);
+            qq += __shfl_xor(qq, 32);
+            const float rs = 1.0f / sqrtf(qq * invT + 1e-5f);      // biased variance, eps 1e-5 (InstanceNorm1d defaults)
+            if (kg == 0) rstd_io[(size_t)clip * N + col] = rs;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int row = m * 16 + 4 * kg + e;
-                const float u = (acc[m][e] - mean) * rs;
-                const float o = row < Tp ? (u > 0.f ? u : 0.2f * u) : 0.f;
-                acc[m][e] = o;
-                omax = fmaxf(omax, fabsf(o));
-                C[(size_t)(bm + row) * ldc + col] = o;
-            }
-    } else {
-        // X3_BWD: acc = dL/dA of the previous block's output (read from `act`, post-activation);
-        //         C = dL/dZ = rstd * (dU - mean_t dU - u * mean_t(dU*u)),  dU = acc * lrelu'(u)
-        const float rs = rstd_io[(size_t)clip * N + col];
-        float s1 = 0.f, s2 = 0.f;
-        float u[MT][4];
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+                for (int e = 0; e < 4; ++e) {
+                    const int row = m * 16 + 4 * kg + e;
+                    const float u = (acc[m][n][e] - mean) * rs;
+                    const float o = row < Tp ? (u > 0.f ? u : 0.2f * u) : 0.f;
+                    acc[m][n][e] = o;
+                    omax = fmaxf(omax, fabsf(o));
+                    C[(size_t)(bm + row) * ldc + col] = o;
+                }
+        } else {
+            // X3_BWD: acc = dL/dA of the previous block's output (read from `act`, post-activation);
+            //         C = dL/dZ = rstd * (dU - mean_t dU - u * mean_t(dU*u)),  dU = acc * lrelu'(u)
+            const float rs = rstd_io[(size_t)clip * N + col];
+            float s1 = 0.f, s2 = 0.f;
+            float u[MT][4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int row = m * 16 + 4 * kg + e;
-                // unconditional load (padding rows exist and hold zeros): a branch here would serialise the loads
-                const float av = act[(size_t)(bm + row) * ldc + col];
-                const bool valid = row < Tp;
-                const float uv = valid ? (av > 0.f ? av : av * 5.0f) : 0.f;                 // invert LeakyReLU(0.2)
-                const float du = valid ? acc[m][e] * unscale * (av > 0.f ? 1.f : 0.2f) : 0.f;
-                acc[m][e] = du;
-                u[m][e] = uv;
-                s1 += du;
-                s2 += du * uv;
-            }
-        s1 += __shfl_xor(s1, 16);
-        s1 += __shfl_xor(s1, 32);
-        s2 += __shfl_xor(s2, 16);
-        s2 += __shfl_xor(s2, 32);
-        const float m1 = s1 * invT, m2 = s2 * invT;
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+                for (int e = 0; e < 4; ++e) {
+                    const int row = m * 16 + 4 * kg + e;
+                    // unconditional load (padding rows exist and hold zeros): a branch here would serialise the loads
+                    const float av = act[(size_t)(bm + row) * ldc + col];
+                    const bool valid = row < Tp;
+                    const float uv = valid ? (av > 0.f ? av : av * 5.0f) : 0.f;                 // invert LeakyReLU(0.2)
+                    const float du = valid ? acc[m][n][e] * unscale * (av > 0.f ? 1.f : 0.2f) : 0.f;
+                    acc[m][n][e] = du;
+                    u[m][e] = uv;
+                    s1 += du;
+                    s2 += du * uv;
+                }
+            s1 += __shfl_xor(s1, 16);
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 16);
+            s2 += __shfl_xor(s2, 32);
+            const float m1 = s1 * invT, m2 = s2 * invT;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int row = m * 16 + 4 * kg + e;
-                const float o = row < Tp ? rs * (acc[m][e] - m1 - u[m][e] * m2) : 0.f;
-                omax = fmaxf(omax, fabsf(o));
-                C[(size_t)(bm + row) * ldc + col] = o;
-            }
-    }
-    if (amax_out) {
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o));
-        if (lane == 0) amax_out[(size_t)clip * 64 + slab_ * 8 + wave] = omax;
+                for (int e = 0; e < 4; ++e) {
+                    const int row = m * 16 + 4 * kg + e;
+                    const float o = row < Tp ? rs * (acc[m][n][e] - m1 - u[m][e] * m2) : 0.f;
+                    omax = fmaxf(omax, fabsf(o));
+                    C[(size_t)(bm + row) * ldc + col] = o;
+                }
+        }
+        if (amax_out) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o));
+            if (lane == 0) amax_out[(size_t)clip * 64 + (col >> 4)] = omax;
+        }
     }
     if (EPI == X3_FWD_LAST) {
-        // acc[m][e] holds this block's output (zero in padding rows).  The next conv block is the skinny last one (CL <= 48
-        // channels): its K = this N is split over the column slabs, so this workgroup contributes the partial
+        // acc[m][n][e] holds this block's output (zero in padding rows).  The next conv block is the skinny last one (CL <= 48
+        // channels): its K = this N is split over the workgroups' column slabs, so this workgroup contributes the partial
         // z_part[slab] = out[:, slab] * Wlast[:, slab]^T, computed on the bf16 pipe with the exact three-way split (operands
-        // of gemm_x3.hip's pack: the tile is re-laid as A fragments (k = column) through LDS).  Wave w takes K32 step w>>1 of
-        // the slab's 128 columns and half w&1 of the row tiles; the four t-partials are then summed through LDS.
-        const int slab = bn >> 7, KS2L = N >> 5, ncl = (CL + 15) >> 4;
-        const int tq = wave >> 1, mh = wave & 1;
-        bf16x8 bl[3][3];
-#pragma unroll
-        for (int n = 0; n < 3; ++n)
-            if (n < ncl) {
-#pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    bl[n][p] = __builtin_bit_cast(bf16x8, Lpk[(((size_t)n * KS2L + 4 * slab + tq) * 3 + p) * 64 + lane]);
-            }
+        // of gemm_x3.hip's pack: the tile is re-laid as A fragments (k = column) through LDS).  The slab has KT = SLABW / 32
+        // K32 steps; work item (tq, mh) = (K32 step, half of the row tiles); wave w takes mh = w & 1 and the steps
+        // tq = (w >> 1) + j NW/2, summing them in registers; the NW/2 partials per half then meet in LDS.
+        constexpr int KT = SLABW / 32;
+        const int KS2L = N >> 5, ncl = (CL + 15) >> 4;
+        const int mh = wave & 1;
         __syncthreads();                                  // every wave is done with the staging buffers
         float* const T = reinterpret_cast<float*>(lds);
-        constexpr int TP = 132;
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int n = 0; n < NTW; ++n)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) T[(16 * m + 4 * kg + e) * TP + 16 * wave + r16] = acc[m][e];
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) T[(16 * m + 4 * kg + e) * TPITCH + (wave * NTW + n) * 16 + r16] = acc[m][n][e];
         __syncthreads();
         f32x4 zt[MH][3];
 #pragma unroll
-        for (int mm = 0; mm < MH; ++mm) {
+        for (int mm = 0; mm < MH; ++mm)
 #pragma unroll
             for (int n = 0; n < 3; ++n) zt[mm][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const float* src = T + (16 * (mh * MH + mm) + r16) * TP + 32 * tq + 8 * kg;
-            const float4 x0 = *reinterpret_cast<const float4*>(src), x1 = *reinterpret_cast<const float4*>(src + 4);
-            uint4 q0, q1, q2;
-            split_pair(x0.x, x0.y, q0.x, q1.x, q2.x);
-            split_pair(x0.z, x0.w, q0.y, q1.y, q2.y);
-            split_pair(x1.x, x1.y, q0.z, q1.z, q2.z);
-            split_pair(x1.z, x1.w, q0.w, q1.w, q2.w);
-            bf16x8 a[3];
-            a[0] = __builtin_bit_cast(bf16x8, q0); a[1] = __builtin_bit_cast(bf16x8, q1); a[2] = __builtin_bit_cast(bf16x8, q2);
 #pragma unroll
-            for (int term = 0; term < 6; ++term) {
-                const int pa = term == 0 ? 2 : (term == 1 || term == 3) ? 1 : 0;
-                const int pb = term == 2 ? 2 : (term == 1 || term == 4) ? 1 : 0;
+        for (int j = 0; j < (2 * KT) / NW; ++j) {
+            const int tq = (wave >> 1) + j * (NW / 2);
+            bf16x8 bl[3][3];
 #pragma unroll
-                for (int n = 0; n < 3; ++n)
-                    if (n < ncl) zt[mm][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[pa], bl[n][pb], zt[mm][n], 0, 0, 0);
+            for (int n = 0; n < 3; ++n)
+                if (n < ncl) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        bl[n][p] = __builtin_bit_cast(bf16x8, Lpk[(((size_t)n * KS2L + KT * slab_ + tq) * 3 + p) * 64 + lane]);
+                }
+#pragma unroll
+            for (int mm = 0; mm < MH; ++mm) {
+                const float* src = T + (16 * (mh * MH + mm) + r16) * TPITCH + 32 * tq + 8 * kg;
+                const float4 x0 = *reinterpret_cast<const float4*>(src), x1 = *reinterpret_cast<const float4*>(src + 4);
+                uint4 q0, q1, q2;
+                split_pair(x0.x, x0.y, q0.x, q1.x, q2.x);
+                split_pair(x0.z, x0.w, q0.y, q1.y, q2.y);
+                split_pair(x1.x, x1.y, q0.z, q1.z, q2.z);
+                split_pair(x1.z, x1.w, q0.w, q1.w, q2.w);
+                bf16x8 a[3];
+                a[0] = __builtin_bit_cast(bf16x8, q0); a[1] = __builtin_bit_cast(bf16x8, q1); a[2] = __builtin_bit_cast(bf16x8, q2);
+#pragma unroll
+                for (int term = 0; term < 6; ++term) {
+                    const int pa = term == 0 ? 2 : (term == 1 || term == 3) ? 1 : 0;
+                    const int pb = term == 2 ? 2 : (term == 1 || term == 4) ? 1 : 0;
+#pragma unroll
+                    for (int n = 0; n < 3; ++n)
+                        if (n < ncl) zt[mm][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[pa], bl[n][pb], zt[mm][n], 0, 0, 0);
+                }
             }
         }
         __syncthreads();                                  // all fragment reads done: the buffer becomes the partial store
@@ -473,13 +517,13 @@ __global__ __launch_bounds__(512, RG <= 3 ? 4 : 2) void gemm_clip_h2_kernel(
         __syncthreads();
         if (wave < MT) {
             const int smh = wave / MH, smm = wave % MH;   // this wave finishes row tile `wave`
-            float* zp = zpart + (size_t)slab * ((size_t)(ntiles / tiles_n) * 32 * RG * CL) + (size_t)(bm + 16 * wave + 4 * kg) * CL;
+            float* zp = zpart + (size_t)slab_ * ((size_t)(ntiles / tiles_n) * 32 * RG * CL) + (size_t)(bm + 16 * wave + 4 * kg) * CL;
 #pragma unroll
             for (int n = 0; n < 3; ++n)
                 if (n < ncl) {
                     f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
+                    for (int q = 0; q < NW / 2; ++q)
                         t += *reinterpret_cast<const f32x4*>(lds + (size_t)(((2 * q + smh) * MH + smm) * 3 + n) * FRAG + lane * 16);
                     if (16 * n + r16 < CL) {
 #pragma unroll
@@ -494,21 +538,30 @@ bool gemm_clip_h2_supported(int nwm, int N, int K, int lda) {
     return nwm >= 1 && nwm <= 4 && N % 128 == 0 && K % 64 == 0 && K <= 1024 && lda % 4 == 0;
 }
 
+// Wave arrangement: 8 waves x 1 tile (128-column slabs, two workgroups per CU).  Measured alternatives on the five launches of
+// an iteration at B = 256 (kernel trace of the launches alone, us): 8 x 1 543; 16 x 1 (256-column slabs, one 1024-thread
+// workgroup per CU: half the A staging per MFMA) 510 -- but no difference inside the embed loop (1.025 vs 1.026 ms per iteration,
+// alternating runs on one box); 8 x 2 (two tiles per wave, 150 VGPRs) 548; the same GEMM on v_mfma_f32_32x32x16_f16 (a wave =
+// all rows x 32 columns: half the MFMA issues, LDS fragment reads and staging per multiply-add, at the 128-VGPR limit) 565;
+// B fragments two K32 steps ahead instead of one: no change.  DESIGN.md section 4 has the counters behind this.
+int gemm_clip_h2_slab_width(int, int, int) { return 128; }
+
 // Bpk: launch_h2_pack image of Wt [N][K]; amax_in: [B][64] partial maxima of A's clips (K/16 valid per clip); amax_out: the
-// same for C ([B][64], N/16 written per clip) or null; lastpk / zpart / CL as launch_gemm_clip_x3 (gemm_x3.hip's pack)
+// same for C ([B][64], N/16 written per clip) or null; lastpk / zpart / CL as launch_gemm_clip_x3 (gemm_x3.hip's pack), with
+// N / gemm_clip_h2_slab_width(nwm, N, B) partial slabs
 void launch_gemm_clip_h2(const float* A, int lda, const void* Bpk, const float* amax_in, float* amax_out, const float* bias,
                          float* C, int ldc, int B, int nwm, int Tp, int N, int K, int epi, float* rstd_io, const float* act,
                          hipStream_t st, const void* lastpk, float* zpart, int CL) {
-    const int tn = N / 128;
     const float* binv = h2_inv_scale(Bpk, N, K);
     if (epi == X3_FWD && lastpk && zpart) epi = X3_FWD_LAST;
-#define HK(M_, E_) hipLaunchKernelGGL((gemm_clip_h2_kernel<M_, E_>), dim3(tn * B), dim3(512), 0, st, A, lda, (const u32x4*)Bpk,     \
-                                      binv, amax_in, amax_out, bias, C, ldc, Tp, N, K, tn, tn * B, rstd_io, act,                   \
-                                      (const u32x4*)lastpk, zpart, CL)
-#define HM(E_) switch (nwm) { case 1: HK(1, E_); break; case 2: HK(2, E_); break; case 3: HK(3, E_); break; default: HK(4, E_); break; }
-    if (epi == X3_FWD) { HM(X3_FWD) } else if (epi == X3_BWD) { HM(X3_BWD) } else if (epi == X3_FWD_LAST) { HM(X3_FWD_LAST) }
-    else { HM(X3_PLAIN) }
-#undef HM
+    const int tn = N / 128;
+#define HK(M_, E_, W_) hipLaunchKernelGGL((gemm_clip_h2_kernel<M_, E_, W_, 1>), dim3(tn * B), dim3(64 * W_), 0, st, A, lda,         \
+                                          (const u32x4*)Bpk, binv, amax_in, amax_out, bias, C, ldc, Tp, N, K, tn, tn * B, rstd_io,  \
+                                          act, (const u32x4*)lastpk, zpart, CL)
+#define HE(M_, W_) if (epi == X3_FWD) { HK(M_, X3_FWD, W_); } else if (epi == X3_BWD) { HK(M_, X3_BWD, W_); }                        \
+                   else if (epi == X3_FWD_LAST) { HK(M_, X3_FWD_LAST, W_); } else { HK(M_, X3_PLAIN, W_); }
+    switch (nwm) { case 1: HE(1, 8) break; case 2: HE(2, 8) break; case 3: HE(3, 8) break; default: HE(4, 8) break; }
+#undef HE
 #undef HK
 }
 

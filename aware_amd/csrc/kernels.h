@@ -133,6 +133,7 @@ size_t h2_packed_bytes(int N, int K);
 void launch_h2_pack(const float* Wt_dev, int ldw, int N, int K, void* out, hipStream_t st);   // device -> device
 void launch_clip_amax(const float* A, int lda, int K, int rows_per_clip, int B, float* amax, hipStream_t st);
 bool gemm_clip_h2_supported(int nwm, int N, int K, int lda);
+int gemm_clip_h2_slab_width(int nwm, int N, int B);     // columns per workgroup (FWD_LAST: N / width partial slabs in zpart)
 // amax_in: [B][64] partial maxima of |A| per clip (K/16 valid); amax_out: [B][64] the same of C (N/16 written) or null
 void launch_gemm_clip_h2(const float* A, int lda, const void* Bpk, const float* amax_in, float* amax_out, const float* bias,
                          float* C, int ldc, int B, int nwm, int Tp, int N, int K, int epi, float* rstd_io, const float* act,

@@ -10,7 +10,7 @@ iters = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 graph = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 n = 48000
 plan = rt.Plan()
-pipe = "f32" if len(sys.argv) > 4 and sys.argv[4] == "f32" else "bf16x3"
+pipe = sys.argv[4] if len(sys.argv) > 4 and sys.argv[4] in ("f32", "bf16x3", "f16x2") else "f16x2"
 dsp = sys.argv[6] if len(sys.argv) > 6 else "stream"
 det = AWAREDetectorNet().device_weights(plan)
 batch = rt.Batch([n] * B)
