@@ -660,6 +660,10 @@ static int det_forward(const aware_detector* d, const aware_batch* b, const floa
         return pipe == 0 && nwm0 && d->wh2[l] && d->ch[l + 1] >= 128 && (d->ch[l + 1] / 128) * b->B >= kH2MinGrid &&
                gemm_clip_h2_supported(nwm0, d->ch[l + 1], d->ch[l], d->ch[l]);
     };
+    auto h2_rag = [&](int l) {
+        return pipe == 0 && !nwm0 && d->wh2[l] && d->ch[l + 1] >= 128 && gemm_clip_h2_supported(1, d->ch[l + 1], d->ch[l], d->ch[l]) &&
+               !(l == d->n_layers - 1 && d->ch[l + 1] <= 64);
+    };
     bool cur_max = false;            // o.amax[l] holds the maxima of the current layer input
     if (mel_front_applies(d, b, pipe)) {
         // uniform batch that fills the chip with one workgroup per clip: the whole mel block in one launch
@@ -711,6 +715,14 @@ static int det_forward(const aware_detector* d, const aware_batch* b, const floa
                                  nullptr, st);
                 LAUNCHCHK(); PROF(K_GEMM_CLIP_FWD);
             }
+        } else if (h2_rag(l)) {
+            // ragged batch / long clips on the default pipe: the f16 two-term kernel, clips walked in chunks of rows
+            if (!cur_max) { launch_ragged_amax(x, ci, ci, b->d_frame_off, b->d_pool_off, b->B, o.amax[l], st); LAUNCHCHK(); PROF(K_MISC); }
+            const bool next_h2 = l + 1 < d->n_layers && h2_rag(l + 1);
+            launch_gemm_ragged_h2(x, ci, d->wh2[l], o.amax[l], next_h2 ? o.amax[l + 1] : nullptr, d->bias[l], o.act[l], co, b->B,
+                                  b->d_frame_off, b->d_pool_off, b->d_order, co, ci, 1, o.rstd[l], nullptr, st);
+            cur_max = next_h2;
+            LAUNCHCHK(); PROF(K_GEMM_X3_FWD);
         } else if (!nwm && pipe != 1 && co >= 128 && d->wpk[l] && gemm_clip_x3_supported(1, co, ci, ci)) {
             // ragged batch / clips longer than the uniform kernel's tile: conv + InstanceNorm + LeakyReLU in one launch,
             // clips walked in chunks of rows (gemm_ragged_x3_kernel)
@@ -825,6 +837,10 @@ static int det_forward_backward(const aware_detector* d, const aware_batch* b, c
         return pipe == 0 && nwm && l > 0 && d->wTh2[l] && d->ch[l] >= 128 && (d->ch[l] / 128) * b->B >= kH2MinGrid &&
                gemm_clip_h2_supported(nwm, d->ch[l], d->ch[l + 1], d->ch[l + 1]);
     };
+    auto h2_rag_bwd = [&](int l) {
+        return pipe == 0 && !nwm && l > 0 && l < nl && d->wTh2[l] && d->ch[l] >= 128 && d->ch[l + 1] >= 128 &&
+               gemm_clip_h2_supported(1, d->ch[l], d->ch[l + 1], d->ch[l + 1]);
+    };
     if (fused_readout) {
         launch_readout_x3(db.act[nl - 2], d->ch[nl - 1], db.zpart, db.zslabs, d->bias[nl - 1], d->lastTpk,
                           db.rstd[nl - 2], G.target, db.pred, G.loss, G.best_loss, G.improved, G.step, dA, b->B,
@@ -891,9 +907,22 @@ static int det_forward_backward(const aware_detector* d, const aware_batch* b, c
             }
         } else if (l == nl - 1 && last_k64) {
             dz_ready = true;
+            const bool next_h2 = h2_rag_bwd(l - 1);
             launch_readout_grad_ragged_x3(db.act[l - 1], ci, dA, d->lastTpk, db.rstd[l - 1], dB, b->d_frame_off, b->d_pool_off,
-                                          b->d_order, b->B, st);
+                                          b->d_order, b->B, st, next_h2 ? gB : nullptr);
+            g_cur = next_h2;
             LAUNCHCHK(); PROF(K_GEMM_X3_BWD);
+            float* t2 = gA; gA = gB; gB = t2;
+        } else if (h2_rag_bwd(l)) {
+            // ragged batch: data-gradient GEMM + backward of block l-1's InstanceNorm + LeakyReLU in one launch (f16 two-term)
+            dz_ready = true;
+            if (!g_cur) { launch_ragged_amax(dA, co, co, b->d_frame_off, b->d_pool_off, b->B, gA, st); LAUNCHCHK(); PROF(K_MISC); }
+            const bool next_h2 = h2_rag_bwd(l - 1);
+            launch_gemm_ragged_h2(dA, co, d->wTh2[l], gA, next_h2 ? gB : nullptr, nullptr, dB, ci, b->B, b->d_frame_off, b->d_pool_off,
+                                  b->d_order, ci, co, 2, db.rstd[l - 1], db.act[l - 1], st);
+            g_cur = next_h2;
+            LAUNCHCHK(); PROF(K_GEMM_X3_BWD);
+            float* t2 = gA; gA = gB; gB = t2;
         } else if (!nwm && pipe != 1 && l > 0 && ci >= 128 && d->wTpk[l] && gemm_clip_x3_supported(1, ci, co, co)) {
             // ragged batch: data-gradient GEMM + backward of block l-1's InstanceNorm + LeakyReLU in one launch
             dz_ready = true;

@@ -534,6 +534,325 @@ __global__ __launch_bounds__(64 * NW, (NW == 16) ? 4 : (NTW == 1 && RG <= 3) ? 4
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Ragged batches: the same conv block / data-gradient GEMM for clips of ANY length in ONE launch (the structure of
+// gemm_ragged_x3_kernel, gemm_x3.hip: a workgroup owns one clip x 128 columns and walks the clip's pooled rows in chunks of two
+// or three 32-row groups; a clip of one chunk gets the single-pass fused epilogue, a longer one two passes with the
+// InstanceNorm statistics carried in registers).  The clip's scale comes from amax_in as in the uniform kernel; the partial
+// maxima of the output (per 16-column group, over all chunks) go to amax_out.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kRaggedRGh = 3;           // largest chunk, in 32-row groups
+extern __shared__ __attribute__((aligned(16))) unsigned char h2_dyn_lds[];
+
+template <class T>
+__device__ __forceinline__ T* h2_uniform_ptr(T* p) {       // (see uniform_ptr in gemm_x3.hip)
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (T*)(__attribute__((address_space(1))) T*)(((unsigned long long)hi << 32) | lo);
+}
+
+// one chunk: rows [bm, bm + 32 RG) of which `rows` are valid.  st0/st1/st2: forward (count, mean, M2) of the column; backward
+// (unused, sum dU, sum dU*u) in-lane partial sums; omax: running max |stored value| of this lane's column (single-pass clips)
+template <int RG, int EPI>
+__device__ __attribute__((noinline)) void h2_ragged_chunk(const bool SINGLE, const float* __restrict__ A, int lda,
+                                                          const u32x4* __restrict__ Bpk, const float* __restrict__ bias,
+                                                          float* __restrict__ C, int ldc, int N, int K, int bm, int rows,
+                                                          int store_rows, int bn, float* __restrict__ rstd_clip,
+                                                          const float* __restrict__ act, float ascale, float unscale, float& st0,
+                                                          float& st1, float& st2, float& omax) {
+    unsigned char* lds = h2_dyn_lds;
+    A = h2_uniform_ptr(A); Bpk = h2_uniform_ptr(Bpk); bias = h2_uniform_ptr(bias); C = h2_uniform_ptr(C);
+    rstd_clip = h2_uniform_ptr(rstd_clip); act = h2_uniform_ptr(act);
+    lda = __builtin_amdgcn_readfirstlane(lda); ldc = __builtin_amdgcn_readfirstlane(ldc);
+    N = __builtin_amdgcn_readfirstlane(N); K = __builtin_amdgcn_readfirstlane(K);
+    bm = __builtin_amdgcn_readfirstlane(bm); bn = __builtin_amdgcn_readfirstlane(bn);
+    rows = __builtin_amdgcn_readfirstlane(rows); store_rows = __builtin_amdgcn_readfirstlane(store_rows);
+    ascale = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ascale)));
+    constexpr int MT = 2 * RG;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, kg = lane >> 4;
+    f32x4 acc[MT][1];
+    h2_tile_gemm<RG, 8, 1>(A, lda, Bpk, K, bm, bn, lds, acc, store_rows, ascale);
+    const int col = bn + wave * 16 + r16;
+    const float invR = 1.0f / (float)rows;
+    if (EPI == X3_FWD) {
+        const float bv = bias ? bias[col] : 0.f;
+        float s = 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[m][0][e] = acc[m][0][e] * unscale + bv;
+                if (m * 16 + 4 * kg + e < rows) s += acc[m][0][e];
+            }
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        const float mean = s * invR;
+        float qq = 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (m * 16 + 4 * kg + e < rows) { const float d = acc[m][0][e] - mean; qq += d * d; }
+        qq += __shfl_xor(qq, 16);
+        qq += __shfl_xor(qq, 32);
+        if (SINGLE) {
+            const float rs = 1.0f / sqrtf(qq * invR + 1e-5f);      // biased variance, eps 1e-5 (InstanceNorm1d defaults)
+            if (kg == 0) rstd_clip[col] = rs;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = m * 16 + 4 * kg + e;
+                    const float u = (acc[m][0][e] - mean) * rs;
+                    const float o = row < rows ? (u > 0.f ? u : 0.2f * u) : 0.f;
+                    omax = fmaxf(omax, fabsf(o));
+                    if (row < store_rows) C[(size_t)(bm + row) * ldc + col] = o;
+                }
+        } else {
+            // raw conv output now, statistics merged across the clip's chunks (Chan et al.)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = m * 16 + 4 * kg + e;
+                    if (row < store_rows) C[(size_t)(bm + row) * ldc + col] = row < rows ? acc[m][0][e] : 0.f;
+                }
+            const float nc = (float)rows, nt = st0 + nc, dl = mean - st1;
+            st2 = st2 + qq + dl * dl * (st0 * nc / nt);
+            st1 = st1 + dl * (nc / nt);
+            st0 = nt;
+        }
+    } else {      // X3_BWD
+        float s1 = 0.f, s2 = 0.f;
+        float u[MT][4];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = m * 16 + 4 * kg + e;
+                const float av = act[(size_t)(bm + min(row, store_rows - 1)) * ldc + col];   // unconditional (clamped, masked below)
+                const bool valid = row < rows;
+                const float uv = valid ? (av > 0.f ? av : av * 5.0f) : 0.f;                 // invert LeakyReLU(0.2)
+                const float du = valid ? acc[m][0][e] * unscale * (av > 0.f ? 1.f : 0.2f) : 0.f;
+                acc[m][0][e] = du;
+                u[m][e] = uv;
+                s1 += du;
+                s2 += du * uv;
+            }
+        if (SINGLE) {
+            const float rs = rstd_clip[col];
+            s1 += __shfl_xor(s1, 16);
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 16);
+            s2 += __shfl_xor(s2, 32);
+            const float m1 = s1 * invR, m2 = s2 * invR;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = m * 16 + 4 * kg + e;
+                    const float o = row < rows ? rs * (acc[m][0][e] - m1 - u[m][e] * m2) : 0.f;
+                    omax = fmaxf(omax, fabsf(o));
+                    if (row < store_rows) C[(size_t)(bm + row) * ldc + col] = o;
+                }
+        } else {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = m * 16 + 4 * kg + e;
+                    if (row < store_rows) C[(size_t)(bm + row) * ldc + col] = acc[m][0][e];          // dU (zero in padding rows)
+                }
+            st1 += s1;
+            st2 += s2;
+        }
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 4) void gemm_ragged_h2_kernel(const float* __restrict__ A, int lda, const u32x4* __restrict__ Bpk,
+                                                                const float* __restrict__ binv, const float* __restrict__ amax_in,
+                                                                float* __restrict__ amax_out, const float* __restrict__ bias,
+                                                                float* __restrict__ C, int ldc, const int* __restrict__ frame_off,
+                                                                const int* __restrict__ pool_off, const int* __restrict__ order, int N,
+                                                                int K, int tiles_n, int ntiles, float* __restrict__ rstd_io,
+                                                                const float* __restrict__ act) {
+    // blocks b and b + 8 share an XCD (observed round-robin placement; speed only): the slabs of one clip stay on one XCD,
+    // clips are dealt to the XCDs round-robin and dispatched longest first (gemm_ragged_x3_kernel has the measurements)
+    int clip, slab;
+    {
+        const int id = blockIdx.x, nclips = ntiles / tiles_n;
+        if ((nclips & 7) == 0) {
+            const int j = id >> 3;
+            clip = (j / tiles_n) * 8 + (id & 7);
+            slab = j % tiles_n;
+        } else {
+            clip = id / tiles_n;
+            slab = id % tiles_n;
+        }
+        if (order) clip = order[clip];
+    }
+    const int bn = slab * 128;
+    const int Tp = (frame_off[clip + 1] - frame_off[clip]) / 2;
+    const int row0 = pool_off[clip];
+    if (Tp < 1) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int col = bn + wave * 16 + r16;
+    float am = lane < (K >> 4) ? amax_in[(size_t)clip * 64 + lane] : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
+    const float ascale = h2_scale_for(am);
+    const float unscale = h2_pow2_inverse(ascale) * binv[col];
+    const int G = (Tp + 31) >> 5;                                   // 32-row groups of the clip
+    const int nchunk = (G + kRaggedRGh - 1) / kRaggedRGh;
+    const int gbase = G / nchunk, grem = G % nchunk;                // balanced: the first `grem` chunks take one group more
+    float* rstd_clip = rstd_io + (size_t)clip * N;
+    float st0 = 0.f, st1 = 0.f, st2 = 0.f, omax = 0.f;
+    const bool single = nchunk == 1;
+    int g0 = 0;
+    for (int c = 0; c < nchunk; ++c) {
+        const int ng = gbase + (c < grem ? 1 : 0);
+        const int bm = row0 + 32 * g0;
+        const int rows = min(32 * ng, Tp - 32 * g0);
+        if (c) __syncthreads();                                     // every wave is done with the previous chunk's staging memory
+        if (ng <= 2) h2_ragged_chunk<2, EPI>(single, A, lda, Bpk, bias, C, ldc, N, K, bm, rows, 32 * ng, bn, rstd_clip, act, ascale, unscale, st0, st1, st2, omax);
+        else h2_ragged_chunk<3, EPI>(single, A, lda, Bpk, bias, C, ldc, N, K, bm, rows, 32 * ng, bn, rstd_clip, act, ascale, unscale, st0, st1, st2, omax);
+        g0 += ng;
+    }
+    if (single) {
+        if (amax_out) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o));
+            if (lane == 0) amax_out[(size_t)clip * 64 + (col >> 4)] = omax;
+        }
+        return;
+    }
+    // ---- pass 2 over the raw tile this workgroup wrote: ROW-MAJOR (lane = 4 consecutive columns, half a wave = one 512-byte
+    // row segment), the per-column statistics handed over through LDS ----
+    const float invT = 1.0f / (float)Tp;
+    const int npad = 32 * G;
+    float* cstat = reinterpret_cast<float*>(h2_dyn_lds);           // [2][128]; the staging memory is free now
+    __syncthreads();                                                // ... once every wave has left its last chunk
+    if (EPI == X3_FWD) {
+        const float rs = 1.0f / sqrtf(st2 * invT + 1e-5f);
+        if (kg == 0) { rstd_clip[col] = rs; cstat[wave * 16 + r16] = st1; cstat[128 + wave * 16 + r16] = rs; }
+    } else {
+        float s1 = st1, s2 = st2;
+        s1 += __shfl_xor(s1, 16);
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 16);
+        s2 += __shfl_xor(s2, 32);
+        if (kg == 0) { cstat[wave * 16 + r16] = s1 * invT; cstat[128 + wave * 16 + r16] = s2 * invT; }
+    }
+    __syncthreads();                                                // statistics in LDS; every wave's raw rows are visible
+    const int c4 = (lane & 31) * 4, rr = 2 * wave + (lane >> 5);
+    const float4 q0 = *reinterpret_cast<const float4*>(cstat + c4), q1 = *reinterpret_cast<const float4*>(cstat + 128 + c4);
+    float* const Cw = C + (size_t)row0 * ldc + bn + c4;
+    float pm = 0.f;                                                 // max |value| of this lane's 4 columns
+    if (EPI == X3_FWD) {
+        for (int r0 = rr; r0 < npad; r0 += 64) {                    // four rows per lane in flight
+            float4 z[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) z[j] = *reinterpret_cast<const float4*>(Cw + (size_t)min(r0 + 16 * j, npad - 1) * ldc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = r0 + 16 * j;
+                if (r >= npad) continue;
+                auto f = [&](float v, float mean, float rs) {
+                    const float u = (v - mean) * rs;
+                    const float o = (r < Tp) ? (u > 0.f ? u : 0.2f * u) : 0.f;
+                    pm = fmaxf(pm, fabsf(o));
+                    return o;
+                };
+                *reinterpret_cast<float4*>(Cw + (size_t)r * ldc) =
+                    make_float4(f(z[j].x, q0.x, q1.x), f(z[j].y, q0.y, q1.y), f(z[j].z, q0.z, q1.z), f(z[j].w, q0.w, q1.w));
+            }
+        }
+    } else {
+        const float4 rs4 = *reinterpret_cast<const float4*>(rstd_clip + bn + c4);
+        const float* const Aw = act + (size_t)row0 * ldc + bn + c4;
+        for (int r0 = rr; r0 < npad; r0 += 64) {
+            float4 du[4], av[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const size_t o = (size_t)min(r0 + 16 * j, npad - 1) * ldc;
+                du[j] = *reinterpret_cast<const float4*>(Cw + o);
+                av[j] = *reinterpret_cast<const float4*>(Aw + o);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = r0 + 16 * j;
+                if (r >= npad) continue;
+                auto f = [&](float d, float a, float rs, float m1, float m2) {
+                    const float uv = a > 0.f ? a : a * 5.0f;
+                    const float o = (r < Tp) ? rs * (d - m1 - uv * m2) : 0.f;
+                    pm = fmaxf(pm, fabsf(o));
+                    return o;
+                };
+                *reinterpret_cast<float4*>(Cw + (size_t)r * ldc) =
+                    make_float4(f(du[j].x, av[j].x, rs4.x, q0.x, q1.x), f(du[j].y, av[j].y, rs4.y, q0.y, q1.y),
+                                f(du[j].z, av[j].z, rs4.z, q0.z, q1.z), f(du[j].w, av[j].w, rs4.w, q0.w, q1.w));
+            }
+        }
+    }
+    if (amax_out) {
+        // the 16-column group of a lane is (lane & 31) >> 2: its four lanes in both half-waves, then the eight waves through LDS
+        pm = fmaxf(pm, __shfl_xor(pm, 1));
+        pm = fmaxf(pm, __shfl_xor(pm, 2));
+        pm = fmaxf(pm, __shfl_xor(pm, 32));
+        float* gm = cstat + 256;                                    // [8 waves][8 groups]
+        if ((lane & 35) == 0) gm[wave * 8 + ((lane & 31) >> 2)] = pm;
+        __syncthreads();
+        if (threadIdx.x < 8) {
+            float m = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) m = fmaxf(m, gm[w * 8 + threadIdx.x]);
+            amax_out[(size_t)clip * 64 + (bn >> 4) + threadIdx.x] = m;
+        }
+    }
+}
+
+// epi: 1 forward, 2 backward (as launch_gemm_ragged_x3); amax_in / amax_out as launch_gemm_clip_h2
+void launch_gemm_ragged_h2(const float* A, int lda, const void* Bpk, const float* amax_in, float* amax_out, const float* bias,
+                           float* C, int ldc, int B, const int* frame_off, const int* pool_off, const int* order, int N, int K,
+                           int epi, float* rstd_io, const float* act, hipStream_t st) {
+    const int tn = N / 128;
+    const float* binv = h2_inv_scale(Bpk, N, K);
+    constexpr size_t kLds = 2 * 2 * 2 * (2 * kRaggedRGh) * 1024;      // two K tiles of the tallest chunk
+    if (epi == X3_FWD)
+        hipLaunchKernelGGL((gemm_ragged_h2_kernel<X3_FWD>), dim3(tn * B), dim3(512), kLds, st, A, lda, (const u32x4*)Bpk, binv, amax_in,
+                           amax_out, bias, C, ldc, frame_off, pool_off, order, N, K, tn, tn * B, rstd_io, act);
+    else
+        hipLaunchKernelGGL((gemm_ragged_h2_kernel<X3_BWD>), dim3(tn * B), dim3(512), kLds, st, A, lda, (const u32x4*)Bpk, binv, amax_in,
+                           amax_out, bias, C, ldc, frame_off, pool_off, order, N, K, tn, tn * B, rstd_io, act);
+}
+
+// per-clip max |x| over the clip's pooled rows (ragged layout), into the partial layout: entry 0 = the maximum, 1 .. K/16-1 = 0
+__global__ __launch_bounds__(256) void ragged_amax_kernel(const float* __restrict__ A, int lda, int K, const int* __restrict__ frame_off,
+                                                           const int* __restrict__ pool_off, float* __restrict__ amax) {
+    __shared__ float red[4];
+    const int clip = blockIdx.x, tid = threadIdx.x;
+    const int Tp = (frame_off[clip + 1] - frame_off[clip]) / 2, row0 = pool_off[clip];
+    const int k4 = K >> 2;
+    float m = 0.f;
+    for (int i = tid; i < Tp * k4; i += 256) {
+        const int r = i / k4, c = i % k4;
+        const float4 v = *reinterpret_cast<const float4*>(A + (size_t)(row0 + r) * lda + 4 * c);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    const int np = K >> 4;
+    if (tid < np) amax[(size_t)clip * 64 + tid] = tid == 0 ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) : 0.f;
+}
+void launch_ragged_amax(const float* A, int lda, int K, const int* frame_off, const int* pool_off, int B, float* amax, hipStream_t st) {
+    hipLaunchKernelGGL(ragged_amax_kernel, dim3(B), dim3(256), 0, st, A, lda, K, frame_off, pool_off, amax);
+}
+
 bool gemm_clip_h2_supported(int nwm, int N, int K, int lda) {
     return nwm >= 1 && nwm <= 4 && N % 128 == 0 && K % 64 == 0 && K <= 1024 && lda % 4 == 0;
 }

@@ -1459,7 +1459,8 @@ __global__ __launch_bounds__(512, 4) void readout_grad_ragged_x3_kernel(const fl
                                                                          const float* __restrict__ rstd_prev, float* __restrict__ dZ,
                                                                          const int* __restrict__ frame_off,
                                                                          const int* __restrict__ pool_off,
-                                                                         const int* __restrict__ order, int G) {
+                                                                         const int* __restrict__ order, int G,
+                                                                         float* __restrict__ amax_out) {
     constexpr int RG = 3, MT = 2 * RG, FRAG = 1024, KSC = 2;
     constexpr int IMG = KSC * 3 * MT * FRAG;
     constexpr int TBYTES = 32 * RG * 132 * 4;
@@ -1485,6 +1486,7 @@ __global__ __launch_bounds__(512, 4) void readout_grad_ragged_x3_kernel(const fl
     const size_t gcol = (size_t)g * 128 + c4;
     const float4 rsp = *reinterpret_cast<const float4*>(rstd_prev + (size_t)clip * ci + gcol);
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1, m1 = s1, m2 = s1;
+    float pm = 0.f;                                      // max |gradient| of this lane's four columns (gemm_h2.hip's scale)
     // always two sweeps (statistics, then results): keeping a chunk's values in registers across the reduction for the
     // single-chunk case costs the 24 VGPRs that decide between one and two workgroups per CU; a short clip's second read of
     // its 49 KB of activation rows comes from L2
@@ -1571,6 +1573,7 @@ __global__ __launch_bounds__(512, 4) void readout_grad_ragged_x3_kernel(const fl
                         o.z = rsp.z * (d.z - m1.z - u.z * m2.z);
                         o.w = rsp.w * (d.w - m1.w - u.w * m2.w);
                     }
+                    pm = fmaxf(fmaxf(pm, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
                     *reinterpret_cast<float4*>(dZ + (size_t)(row0 + row) * ci + gcol) = o;
                 }
             }
@@ -1594,13 +1597,31 @@ __global__ __launch_bounds__(512, 4) void readout_grad_ragged_x3_kernel(const fl
             }
         }
     }
+    if (amax_out) {
+        // partial maxima per 16-column group: the group of a lane is (lane & 31) >> 2 (its four lanes in both half-waves),
+        // then the eight waves through LDS
+        pm = fmaxf(pm, __shfl_xor(pm, 1));
+        pm = fmaxf(pm, __shfl_xor(pm, 2));
+        pm = fmaxf(pm, __shfl_xor(pm, 32));
+        __syncthreads();                                 // `red` is free: every wave has read the column sums
+        float* gm = &red[0][0][0];
+        if ((lane & 35) == 0) gm[wave * 8 + ((lane & 31) >> 2)] = pm;
+        __syncthreads();
+        if (tid < 8) {
+            float m = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) m = fmaxf(m, gm[w * 8 + tid]);
+            amax_out[(size_t)clip * 64 + g * 8 + tid] = m;
+        }
+    }
 }
 
 void launch_readout_grad_ragged_x3(const float* hin, int ci, const float* dZl, const void* WTpk, const float* rstd_prev, float* dZ,
-                                   const int* frame_off, const int* pool_off, const int* order, int B, hipStream_t st) {
+                                   const int* frame_off, const int* pool_off, const int* order, int B, hipStream_t st,
+                                   float* amax_out) {
     const int G = ci / 128;
     hipLaunchKernelGGL(readout_grad_ragged_x3_kernel, dim3(B * G), dim3(512), 0, st, hin, ci, dZl, (const u32x4*)WTpk, rstd_prev, dZ,
-                       frame_off, pool_off, order, G);
+                       frame_off, pool_off, order, G, amax_out);
 }
 
 bool readout_x3_supported(int nwm, int ci, int C) { return nwm >= 1 && nwm <= 4 && ci % 128 == 0 && C >= 2 && C <= 48 && C % 2 == 0; }

@@ -138,6 +138,10 @@ int gemm_clip_h2_slab_width(int nwm, int N, int B);     // columns per workgroup
 void launch_gemm_clip_h2(const float* A, int lda, const void* Bpk, const float* amax_in, float* amax_out, const float* bias,
                          float* C, int ldc, int B, int nwm, int Tp, int N, int K, int epi, float* rstd_io, const float* act,
                          hipStream_t st, const void* lastpk = nullptr, float* zpart = nullptr, int CL = 0);
+void launch_gemm_ragged_h2(const float* A, int lda, const void* Bpk, const float* amax_in, float* amax_out, const float* bias,
+                           float* C, int ldc, int B, const int* frame_off, const int* pool_off, const int* order, int N, int K,
+                           int epi, float* rstd_io, const float* act, hipStream_t st);
+void launch_ragged_amax(const float* A, int lda, int K, const int* frame_off, const int* pool_off, int B, float* amax, hipStream_t st);
 // (Mrows > 0, plain epilogue only: the matrices have Mrows < B*32*nwm rows -- the last row block is partial)
 // the same block for ragged batches / clips of any length (one launch; clips longer than 96 pooled frames in two passes)
 void launch_gemm_ragged_x3(const float* A, int lda, const void* Bpk, const float* bias, float* C, int ldc, int B,
@@ -156,7 +160,8 @@ size_t readout_x3_image_bytes(int B, int nwm);      // scratch `img` of launch_r
 // ragged batches: data gradient of the last conv from dZl (float32 rows, pitch 64, zero K padding: launch_tail with ldz = 64)
 // with the backward of the previous block's InstanceNorm + LeakyReLU; ci % 128 == 0, last conv of at most 64 channels
 void launch_readout_grad_ragged_x3(const float* hin, int ci, const float* dZl, const void* WTpk, const float* rstd_prev, float* dZ,
-                                   const int* frame_off, const int* pool_off, const int* order, int B, hipStream_t st);
+                                   const int* frame_off, const int* pool_off, const int* order, int B, hipStream_t st,
+                                   float* amax_out = nullptr);
 // mel block: InstanceNorm over time, per-clip GlobalStandardize, AvgPool(2,2)
 void launch_mel_norm_fwd(const float* xm, const int* frame_off, const int* pool_off, float* x0, float* stats,
                          float* gstat, float* part, int pstride, int B, int max_frames, hipStream_t st);

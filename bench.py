@@ -346,7 +346,9 @@ def main():
         all_n = sum(breakdown[k][1] for k in gemm_kinds)
         flops_iter = sum(detector_flops_per_clip_iter(t) for t in batch.frames)
         uniform = len(set(batch.frames)) == 1 and batch.frames[0] // 2 <= 128
-        on_h2 = uniform and len(batch.frames) >= 32 and "gemm_x3_fwd" in breakdown   # capi.hip: kH2MinGrid, clip_tile_groups
+        # capi.hip (kH2MinGrid, clip_tile_groups, h2_rag): uniform batches from 32 clips on and every ragged batch run their
+        # conv blocks on the f16 two-term kernels; smaller uniform batches on the bf16x3 latency kernel
+        on_h2 = "gemm_x3_fwd" in breakdown and (not uniform or len(batch.frames) >= 32)
         if on_h2:
             peak = MFMA_BF16_PEAK_TF / 3.0
             peak_note = ("f32-equivalent peak of the f16 two-term kernel (gemm_h2.hip): dense f16 MFMA peak (2.5 PFLOP/s, the bf16 "
@@ -362,10 +364,11 @@ def main():
             fl = 2.0 * rows * (ch[0] * ch[1] + ch[1] * ch[2] + ch[2] * ch[3]) + 2.0 * rows * (ch[3] * ch[2] + ch[2] * ch[1])
             ms = breakdown["gemm_x3_fwd"][0] + breakdown["gemm_x3_bwd"][0]
             nl = breakdown["gemm_x3_fwd"][1] + breakdown["gemm_x3_bwd"][1]
-            kname = "gemm_clip_h2_kernel" if on_h2 else ("gemm_clip_x3_kernel / gemm_clip_x3_small_kernel" if uniform else "gemm_ragged_x3_kernel")
+            kname = ("gemm_clip_h2_kernel" if uniform else "gemm_ragged_h2_kernel") if on_h2 else "gemm_clip_x3_small_kernel"
             name = f"aware::{kname} (forward epilogue x3, backward epilogue x2 per iteration)"
             if not uniform:
-                # the last conv's data gradient of a ragged batch is one more launch of this kind (readout_grad_ragged_x3_kernel)
+                # the last conv's data gradient of a ragged batch is one more launch of this kind (readout_grad_ragged_x3_kernel,
+                # K = 64 on the bf16x3 arithmetic: 2 % of the flops)
                 fl += 2.0 * rows * ch[4] * ch[3]
             per_kernel = {kname + " forward": round(breakdown["gemm_x3_fwd"][0] * 1e3 / breakdown["gemm_x3_fwd"][1], 2),
                           kname + " backward": round(breakdown["gemm_x3_bwd"][0] * 1e3 / breakdown["gemm_x3_bwd"][1], 2)}
