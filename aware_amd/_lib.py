@@ -107,6 +107,8 @@ SIGNATURES = {
     "aware_detector_train_workspace_bytes": (_sz, [_vp, _vp]),
     "aware_detector_weight_gradients": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _vp, _sz, _vp]),
     "aware_detector_update": (_i, [_vp, _vp, C.POINTER(_vp), C.POINTER(_vp)]),
+    "aware_detector_train_gradients": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _vp, _sz, _vp]),
+    "aware_detector_update_device": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), _vp]),
     "aware_detector_create": (_i, [C.POINTER(_vp), _vp, _vp, _i, _i, _pi, C.POINTER(_vp), C.POINTER(_vp)]),
     "aware_detector_destroy": (None, [_vp]),
     "aware_detect_workspace_bytes": (_sz, [_vp, _vp]),

@@ -557,6 +557,35 @@ extern "C" int aware_detector_update(aware_detector* d, const float* mel_basis, 
     if (!d || !mel_basis || !weights) return AWARE_E_BADARG;
     return detector_upload(d, mel_basis, weights, biases, false);
 }
+// EXTENSION (detector training): the same refresh from DEVICE arrays, asynchronous on `stream` -- no host round trip of the
+// 1.68 M parameters: copies, transposes, bf16 three-term and f16 two-term images all rebuilt by kernels.  dev_weights[l]:
+// [Cout][Cin] f32, dev_biases[l]: [Cout] f32 (device pointers in host arrays; biases may be NULL = unchanged).
+extern "C" int aware_detector_update_device(aware_detector* d, const float* const* dev_weights, const float* const* dev_biases,
+                                            void* stream) {
+    if (!d || !dev_weights) return AWARE_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int nl = d->n_layers;
+    for (int l = 0; l < nl; ++l) {
+        const int ci = d->ch[l], co = d->ch[l + 1];
+        if (!dev_weights[l]) return AWARE_E_BADARG;
+        HIPCHK(hipMemcpyAsync(d->w[l], dev_weights[l], (size_t)ci * co * sizeof(float), hipMemcpyDeviceToDevice, st));
+        if (dev_biases && dev_biases[l])
+            HIPCHK(hipMemcpyAsync(d->bias[l], dev_biases[l], (size_t)co * sizeof(float), hipMemcpyDeviceToDevice, st));
+        launch_transpose(d->w[l], d->wT[l], co, ci, st);
+        if (d->wpk[l]) launch_x3_pack_dev(d->w[l], ci, co, ci, co, ci, d->wpk[l], st);
+        if (d->wTpk[l]) launch_x3_pack_dev(d->wT[l], co, ci, co, ci, co, d->wTpk[l], st);
+        if (d->wh2[l]) launch_h2_pack(d->w[l], ci, co, ci, d->wh2[l], st);
+        if (d->wTh2[l]) launch_h2_pack(d->wT[l], co, ci, co, d->wTh2[l], st);
+    }
+    if (d->lastpk) {
+        const int cil = d->ch[nl - 1], col = d->ch[nl], colp = 16 * ((col + 15) / 16);
+        launch_x3_pack_dev(d->w[nl - 1], cil, col, cil, colp, cil, d->lastpk, st);        // rows zero-padded to a multiple of 16
+        launch_x3_pack_dev(d->wT[nl - 1], col, cil, col, cil, 64, d->lastTpk, st);        // k zero-padded to 64
+    }
+    LAUNCHCHK();
+    return AWARE_OK;
+}
+
 extern "C" void aware_detector_destroy(aware_detector* d) {
     if (!d) return;
     if (d->mem) (void)hipFree(d->mem);
@@ -983,13 +1012,38 @@ extern "C" int aware_detector_backward(const aware_detector* d, const aware_batc
 // pointers ([Cout][Cin] and [Cout] f32; entries may be NULL).
 extern "C" size_t aware_detector_train_workspace_bytes(const aware_batch* b, const aware_detector* d) {
     if (!b || !d) return 0;
-    return aware_detector_backward_workspace_bytes(b, d) + (size_t)b->NP * d->maxc * sizeof(float) * 2 + 1024;
+    return aware_detector_backward_workspace_bytes(b, d) + (size_t)b->NP * d->maxc * sizeof(float) * 2 +
+           (size_t)b->NF * kFS * sizeof(float) + 2048;
 }
+static int detector_train_core(const aware_detector* d, const aware_batch* b, const float* mag, const float* target, int loss_kind,
+                               float* loss_out, float* values, float* grad_mag, float* const* grad_weights,
+                               float* const* grad_biases, void* workspace, size_t workspace_bytes, void* stream);
+
+// The same with the loss evaluated inside (ONE forward + backward per step): target [B][n_bits] bipolar, loss_kind an
+// AWARE_LOSS_* of the embed loop (no best-loss bookkeeping), loss_out dev [B] per-clip losses.  The gradients are those of the
+// SUM of the per-clip losses (scale by 1 / clips in the optimiser step for their mean).  grad_mag may be NULL.
+extern "C" int aware_detector_train_gradients(const aware_detector* d, const aware_batch* b, const float* mag, const float* target,
+                                              int loss_kind, float* loss_out, float* values, float* grad_mag,
+                                              float* const* grad_weights, float* const* grad_biases, void* workspace,
+                                              size_t workspace_bytes, void* stream) {
+    if (!d || !b || !mag || !target || !loss_out || !grad_weights || !workspace) return AWARE_E_BADARG;
+    if (loss_kind < 0 || loss_kind > AWARE_LOSS_BER) return AWARE_E_BADARG;
+    return detector_train_core(d, b, mag, target, loss_kind, loss_out, values, grad_mag, grad_weights, grad_biases, workspace,
+                               workspace_bytes, stream);
+}
+
 extern "C" int aware_detector_weight_gradients(const aware_detector* d, const aware_batch* b, const float* mag,
                                                const float* grad_values, float* values, float* grad_mag,
                                                float* const* grad_weights, float* const* grad_biases, void* workspace,
                                                size_t workspace_bytes, void* stream) {
     if (!d || !b || !mag || !grad_values || !grad_mag || !grad_weights || !workspace) return AWARE_E_BADARG;
+    return detector_train_core(d, b, mag, grad_values, AWARE_LOSS_EXTERNAL, nullptr, values, grad_mag, grad_weights, grad_biases,
+                               workspace, workspace_bytes, stream);
+}
+
+static int detector_train_core(const aware_detector* d, const aware_batch* b, const float* mag, const float* target, int loss_kind,
+                               float* loss_out, float* values, float* grad_mag, float* const* grad_weights,
+                               float* const* grad_biases, void* workspace, size_t workspace_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     Carver c(workspace, workspace_bytes);
     DetBufs o;
@@ -999,11 +1053,12 @@ extern "C" int aware_detector_weight_gradients(const aware_detector* d, const aw
     G.d2 = c.take<float>((size_t)b->NP * d->maxc);
     G.tr1 = c.take<float>((size_t)b->NP * d->maxc);
     G.tr2 = c.take<float>((size_t)b->NP * d->maxc);
-    G.loss = c.take<float>(b->B);
+    G.loss = loss_out ? loss_out : c.take<float>(b->B);
+    if (!grad_mag) grad_mag = c.take<float>((size_t)b->NF * kFS);
     if (!c.ok) return AWARE_E_WORKSPACE;
     // padding rows of the gradient ping-pong buffers take part in the row contraction: keep them finite
     HIPCHK(hipMemsetAsync(G.d1, 0, (size_t)b->NP * d->maxc * sizeof(float) * 2, st));
-    G.target = grad_values; G.loss_kind = AWARE_LOSS_EXTERNAL; G.gmag = grad_mag;
+    G.target = target; G.loss_kind = loss_kind; G.gmag = grad_mag;
     G.wgrad = grad_weights; G.bgrad = grad_biases; G.readout = 1; G.pipe = 1;      // exact-f32 pipe for the training step
     int rc = det_forward_backward(d, b, mag, o, G, st);
     if (rc) return rc;
@@ -1405,10 +1460,17 @@ extern "C" int aware_embed_iterate(aware_embed* e, int n_iters, void* stream) {
             for (int i = 0; i < (which ? kGraphIters : 1) && rc == AWARE_OK; ++i) rc = embed_iteration(e, e->cap, 1, nullptr);
             hipGraph_t g = nullptr;
             hipError_t ce = hipStreamEndCapture(e->cap, &g);
-            if (rc) return rc;
-            HIPCHK(ce);
             hipGraphExec_t ge = nullptr;
-            HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            if (rc == AWARE_OK && ce == hipSuccess) ce = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+            if (rc != AWARE_OK || ce != hipSuccess) {
+                // no half-recorded state: drop whatever exists (both graphs) so that a later call records again
+                if (ge) (void)hipGraphExecDestroy(ge);
+                if (g) (void)hipGraphDestroy(g);
+                if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
+                if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
+                if (rc != AWARE_OK) return rc;
+                HIPCHK(ce);
+            }
             if (which) { e->graphN = g; e->gexecN = ge; } else { e->graph = g; e->gexec = ge; }
         }
     }

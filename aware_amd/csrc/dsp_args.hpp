@@ -41,12 +41,13 @@ __device__ __forceinline__ void nadam_clamp_update(float& p, float& mo, float& v
 //   kind 6 adamax          c.x = -lr/bc1;  h0 = 1-beta1, h1 = beta2, h3 = eps
 //   kind 7 adadelta        c.x = -lr;  h1 = rho, h2 = 1-rho, h3 = eps     (mo holds acc_delta, ve square_avg)
 //   kind 0 nadam           c.x, c.y, c.z as nadam_clamp_update (c.z = bc2);  h0..h3 as adam
-//   all but adamw: h4 = weight_decay (L2: grad += wd * param)
+//   all but adamw: h4 = weight_decay (L2: grad += wd * param);  all: h7 = gradient scale (0 = none)
 enum { OPT_NADAM = 0, OPT_ADAM = 1, OPT_ADAMW = 2, OPT_SGD = 3, OPT_RMSPROP = 4, OPT_ADAGRAD = 5, OPT_ADAMAX = 6, OPT_ADADELTA = 7 };
 struct OptHyp { float h[8]; };
 __device__ __forceinline__ void opt_clamp_update(int kind, float& p, float& mo, float& ve, float g, float blo, float bhi,
                                                  const float4& c, const OptHyp& H) {
     const float* h = H.h;
+    if (h[7] != 0.f) g = g * h[7];                 // gradient scale (e.g. 1 / clips of a summed batch gradient); 0 = none
     if (kind == OPT_ADAMW) p = p * c.w;
     else if (h[4] != 0.f) g = g + h[4] * p;
     if (kind == OPT_NADAM) {

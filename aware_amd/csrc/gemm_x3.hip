@@ -74,6 +74,30 @@ void x3_pack(const float* Wt, int N, int K, uint16_t* out) {
                 }
 }
 
+// the same pack on the device (detector training: the weights change every step): element (n, k) of the [N][K] operand is
+// Wt[n * ldw + k] for n < Nvalid, k < Kvalid and 0 otherwise (rows / k zero-padded as the read-out operands need)
+__global__ __launch_bounds__(64) void x3_pack_dev_kernel(const float* __restrict__ Wt, int ldw, int Nvalid, int Kvalid, int KS,
+                                                          u32x4* __restrict__ out) {
+    const int ks = blockIdx.x, nt = blockIdx.y, lane = threadIdx.x;
+    const int n = nt * 16 + (lane & 15), k0 = ks * 32 + 8 * (lane >> 4);
+    unsigned p0[4], p1[4], p2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = k0 + 2 * j;
+        const float x = (n < Nvalid && k < Kvalid) ? Wt[(size_t)n * ldw + k] : 0.f;
+        const float y = (n < Nvalid && k + 1 < Kvalid) ? Wt[(size_t)n * ldw + k + 1] : 0.f;
+        split_pair(x, y, p0[j], p1[j], p2[j]);
+    }
+    u32x4* o = out + ((size_t)(nt * KS + ks) * 3) * 64 + lane;
+    o[0] = u32x4{p0[0], p0[1], p0[2], p0[3]};
+    o[64] = u32x4{p1[0], p1[1], p1[2], p1[3]};
+    o[128] = u32x4{p2[0], p2[1], p2[2], p2[3]};
+}
+void launch_x3_pack_dev(const float* Wt_dev, int ldw, int Nvalid, int Kvalid, int N, int K, void* out, hipStream_t st) {
+    const int KS = (K + 31) / 32;
+    hipLaunchKernelGGL(x3_pack_dev_kernel, dim3(KS, N / 16), dim3(64), 0, st, Wt_dev, ldw, Nvalid, Kvalid, KS, (u32x4*)out);
+}
+
 // The K loop of one tile: acc[m][n] += A[bm + 16 m .. +16)[0..K) * B^T for the wave's 16*NTW columns starting at
 // bn + wave*16*NTW.  `lds` is the workgroup's staging memory (2 * 2 * 3 * 2RG KiB); every wave of the workgroup calls this
 // with the same arguments.  The caller provides a barrier between two calls that reuse `lds`.

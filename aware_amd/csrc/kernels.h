@@ -111,6 +111,7 @@ void launch_gemm_clip(const float* A, int lda, const float* Bt, int ldb, const f
 // ---- gemm_x3.hip: the same clip-aligned GEMM on the bf16 matrix pipe, f32-equivalent (3-way operand split) ----
 size_t x3_packed_bytes(int N, int K);
 void x3_pack(const float* Wt, int N, int K, uint16_t* out);      // host: [N][K] f32 -> fragment-ordered bf16 planes
+void launch_x3_pack_dev(const float* Wt_dev, int ldw, int Nvalid, int Kvalid, int N, int K, void* out, hipStream_t st);   // device -> device
 bool gemm_clip_x3_supported(int nwm, int N, int K, int lda);
 // mel projection + InstanceNorm + GlobalStandardize + AvgPool of a UNIFORM batch of clips of T <= 192 frames in one launch
 // (one workgroup per clip): xm [NF][128] raw mel tile (kept for the backward), x0 pooled tile, stats / gstat as

@@ -230,7 +230,7 @@ def run_folder(folder, embedder, detector, attacks=(), watermark_length: int = 2
         except ValueError as e:
             rec["skipped"].append((p.name, str(e)))
             continue
-        if len(x) * 16000 // sr <= 512:                      # torch.stft's reflect padding needs more than n_fft / 2 samples
+        if -(-len(x) * 16000 // sr) <= 512:      # polyphase output length ceil(n * up / down); torch.stft's reflect padding needs > n_fft / 2
             rec["skipped"].append((p.name, "clip too short"))
             continue
         by_rate.setdefault(sr, []).append((p.name, x))

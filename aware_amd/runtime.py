@@ -275,6 +275,27 @@ def detector_weight_gradients(plan: Plan, det: "DetectorWeights", batch: Batch, 
     return vals, gmag, gw, gb
 
 
+def detector_train_gradients(plan: Plan, det: "DetectorWeights", batch: Batch, mag: torch.Tensor, target: torch.Tensor,
+                             loss: str = "push_extremes", grad_weights=None, grad_biases=None):
+    """EXTENSION (detector training): ONE forward + backward of the network with the loss evaluated on the device
+    (aware_detector_train_gradients): (values [B, n_bits], per-clip losses [B], [dL/dW_l], [dL/db_l]) -- gradients of the SUM
+    of the per-clip losses.  grad_weights / grad_biases: tensors to write into (e.g. views of one flat bucket)."""
+    lib = plan.lib
+    nbytes = lib.aware_detector_train_workspace_bytes(batch.h, det.h)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=mag.device)
+    vals = torch.empty((batch.B, det.n_bits), dtype=torch.float32, device=mag.device)
+    losses = torch.empty((batch.B,), dtype=torch.float32, device=mag.device)
+    ch = det.channels
+    gw = grad_weights or [torch.empty((ch[i + 1], ch[i]), dtype=torch.float32, device=mag.device) for i in range(len(ch) - 1)]
+    gb = grad_biases or [torch.empty((ch[i + 1],), dtype=torch.float32, device=mag.device) for i in range(len(ch) - 1)]
+    pw = (C.c_void_p * len(gw))(*[t.data_ptr() for t in gw])
+    pb = (C.c_void_p * len(gb))(*[t.data_ptr() for t in gb])
+    tg = target.contiguous().float()
+    check(lib.aware_detector_train_gradients(det.h, batch.h, _ptr(mag), _ptr(tg), LOSS_KINDS[loss], _ptr(losses), _ptr(vals), None,
+                                             pw, pb, _ptr(ws), nbytes, _stream()), "aware_detector_train_gradients")
+    return vals, losses, gw, gb
+
+
 class DetectorWeights:
     """Device copy of the frozen detector (aware_detector)."""
 
@@ -306,6 +327,15 @@ class DetectorWeights:
         wp = (C.c_void_p * len(ws))(*[w.ctypes.data for w in ws])
         bp = (C.c_void_p * len(bs))(*[b.ctypes.data for b in bs])
         check(self.lib.aware_detector_update(self.h, C.c_void_p(self._mel.ctypes.data), wp, bp), "aware_detector_update")
+
+    def update_device(self, weights, biases):
+        """EXTENSION (detector training): the same from DEVICE tensors, asynchronous on the current stream -- no host round trip
+        (aware_detector_update_device: copies, transposes and both packed images rebuilt by kernels)."""
+        ws = [w if w.is_contiguous() else w.contiguous() for w in weights]
+        bs = [b if b.is_contiguous() else b.contiguous() for b in biases]
+        wp = (C.c_void_p * len(ws))(*[w.data_ptr() for w in ws])
+        bp = (C.c_void_p * len(bs))(*[b.data_ptr() for b in bs])
+        check(self.lib.aware_detector_update_device(self.h, wp, bp, _stream()), "aware_detector_update_device")
 
     def __del__(self):
         try:

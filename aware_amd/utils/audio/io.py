@@ -23,6 +23,8 @@ def read_wav(path):
         cid, size = data[pos:pos + 4], struct.unpack_from("<I", data, pos + 4)[0]
         chunk = data[pos + 8:pos + 8 + size]
         if cid == b"fmt ":
+            if len(chunk) < 16:
+                raise ValueError(f"{path}: fmt chunk of {len(chunk)} bytes (16 needed)")
             tag, ch, sr, _, align, bits = struct.unpack_from("<HHIIHH", chunk, 0)
             if tag == _EXTENSIBLE and len(chunk) >= 26:
                 tag = struct.unpack_from("<H", chunk, 24)[0]          # first two bytes of the sub-format GUID
@@ -35,6 +37,8 @@ def read_wav(path):
     tag, ch, sr, align, bits = fmt
     if ch < 1:
         raise ValueError(f"{path}: no channels")
+    if bits not in (8, 16, 24, 32, 64):                       # (ADPCM and other sub-byte codings: not PCM samples)
+        raise ValueError(f"{path}: unsupported WAVE format tag {tag} with {bits} bits")
     nbytes = bits // 8
     n = len(body) // (nbytes * ch)
     body = body[:n * nbytes * ch]

@@ -177,6 +177,16 @@ int aware_detector_weight_gradients(const aware_detector* det, const aware_batch
                                     size_t workspace_bytes, void* stream);
 int aware_detector_update(aware_detector* det, const float* mel_basis, const float* const* weights,
                           const float* const* biases);
+/* the step without host round trips: aware_detector_train_gradients evaluates the loss inside (ONE forward + backward; target
+ * [B][n_bits] bipolar, loss_kind 0..5 as the embed loop, loss_out dev [B]; the gradients are those of the SUM of the per-clip
+ * losses; grad_mag may be NULL), aware_detector_update_device rebuilds every device image of the parameters from DEVICE arrays
+ * (asynchronous on `stream`; dev_weights / dev_biases: host arrays of device pointers, biases may be NULL). */
+int aware_detector_train_gradients(const aware_detector* det, const aware_batch* batch, const float* mag, const float* target,
+                                   int loss_kind, float* loss_out, float* values, float* grad_mag,
+                                   float* const* grad_weights, float* const* grad_biases, void* workspace,
+                                   size_t workspace_bytes, void* stream);
+int aware_detector_update_device(aware_detector* det, const float* const* dev_weights, const float* const* dev_biases,
+                                 void* stream);
 
 /* ---- embedder -----------------------------------------------------------------------------------
  * AWAREEmbedder.embed / _optimize (embedding/multibit_embedder.py:70-197), batched and ragged:

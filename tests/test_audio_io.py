@@ -49,3 +49,26 @@ def test_hand_built_pcm24_pcm8_extensible(tmp_path):
     p.write_bytes(b"not a wave file at all")
     with pytest.raises(ValueError):
         io.read_wav(p)
+
+
+def test_malformed_files_raise_value_error(tmp_path):
+    """Everything read_wav cannot decode raises ValueError (run_folder skips such files one by one, scripts/test.py:66-71): a
+    short fmt chunk, a 4-bit ADPCM-style header, a truncated RIFF."""
+    import struct
+    from aware_amd.utils.audio import io
+
+    def riff(fmt_chunk, body=b"\x00" * 64):
+        payload = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt_chunk)) + fmt_chunk + b"data" + struct.pack("<I", len(body)) + body
+        return b"RIFF" + struct.pack("<I", len(payload)) + payload
+
+    cases = {
+        "short_fmt.wav": riff(struct.pack("<HHIIH", 1, 1, 16000, 32000, 2)),                    # 14-byte fmt chunk
+        "adpcm4.wav": riff(struct.pack("<HHIIHH", 2, 1, 16000, 8000, 256, 4)),                   # 4 bits per sample
+        "zero_bits.wav": riff(struct.pack("<HHIIHH", 1, 1, 16000, 0, 0, 0)),
+        "truncated.wav": b"RIFF\x10\x00\x00\x00WA",
+    }
+    for name, blob in cases.items():
+        path = tmp_path / name
+        path.write_bytes(blob)
+        with pytest.raises(ValueError):
+            io.read_wav(str(path))

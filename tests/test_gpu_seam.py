@@ -271,17 +271,50 @@ def test_detector_weight_gradients_extension(env):
         assert rel < 2e-4, (l, rel)
         # the InstanceNorm behind every convolution removes per-channel constants: bias gradients vanish up to rounding
         assert float(gb[l].abs().max()) < 1e-4 * float(ref.abs().max()) * ref.shape[1]
-    # one training step: device and host weights move together, the detector still works
+    # Training steps, everything on the device (one forward + backward with the loss inside, Adam on the flat bucket, the packed
+    # images rebuilt by kernels): against torch autograd + torch.optim.Adam on the oracle's detector with the same objective
+    # (mean over clips of mse - 0.1 mean|raw|, losses.py:38-42) -- losses of three steps and the weights after them.
     from aware_amd.training import DetectorTrainer
     from aware_amd.utils.models import load
     emb2, det2 = load()
     w_before = [w.copy() for w in det2.detection_net.weights]
     bits = torch.randint(0, 2, (2, 20), generator=g).to(torch.int32).cuda()
     tr = DetectorTrainer(det2, lr=1e-3)
-    l0, raw0 = tr.step(rt.Ragged(x, lengths), bits)
-    l1, raw1 = tr.step(rt.Ragged(x, lengths), bits)
-    assert np.isfinite(l0) and np.isfinite(l1) and l1 < l0            # two Adam steps on the same batch reduce its loss
-    assert any(float(np.abs(a - b).max()) > 0 for a, b in zip(w_before, det2.detection_net.weights))
+    mine = [tr.step(rt.Ragged(x, lengths), bits)[0] for _ in range(3)]
+    od2 = O.Detector()
+    pw = [w.clone().requires_grad_(True) for w in od2.ws]
+    pb = [b_.clone().requires_grad_(True) for b_ in od2.bs]
+    od2.ws, od2.bs = pw, pb
+    adam = torch.optim.Adam(pw + pb, lr=1e-3)
+    tg = (2 * bits.cpu().float() - 1)
+    ref_losses = []
+    for _ in range(3):
+        adam.zero_grad()
+        per_clip = []
+        for i, c in enumerate(clips):
+            a = torch.from_numpy(c)[None]
+            m = torch.abs(O.stft(a / torch.amax(torch.abs(a) + 1e-8))).clone()
+            m[:, oe.nonband] = 0.0
+            p = od2.forward(m)[0]
+            per_clip.append(((p - tg[i]) ** 2).mean() - 0.1 * p.abs().mean())
+        loss = torch.stack(per_clip).mean()
+        loss.backward()
+        adam.step()
+        ref_losses.append(float(loss))
+    print("trainer losses", mine, "oracle", ref_losses)
+    np.testing.assert_allclose(mine, ref_losses, atol=2e-5)
+    assert mine[2] < mine[0]                                            # Adam steps on the same batch reduce its loss
+    tr.sync_host()
+    for l in range(4):
+        rel = float(np.linalg.norm(det2.detection_net.weights[l] - pw[l].detach().numpy()) / np.linalg.norm(pw[l].detach().numpy()))
+        moved = float(np.abs(det2.detection_net.weights[l] - w_before[l]).max())
+        print(f"layer {l}: weights after 3 steps rel L2 vs oracle {rel:.2e}, moved by up to {moved:.1e}")
+        assert rel < 2e-5 and moved > 1e-4
     v = det2.detect_batch(clips, 16000)
     assert bool(torch.isfinite(v).all())
+    # the refreshed device images (f32, transposed, bf16x3 and f16x2 packs) are those of the new weights: a detector built
+    # from the synced host copy gives the same outputs
+    from aware_amd.runtime import DetectorWeights
+    fresh = DetectorWeights(plan, det2.detection_net.mel_basis, det2.detection_net.weights, det2.detection_net.biases)
+    np.testing.assert_allclose(v.cpu().numpy(), rt.detect(plan, fresh, batch, x).cpu().numpy(), atol=1e-6)
     np.testing.assert_allclose(v.cpu().numpy(), rt.detect(plan, det2.detection_net.device_weights(plan), batch, x).cpu().numpy(), atol=1e-6)
