@@ -103,7 +103,7 @@ struct aware_detector {
     float* bias[8] = {nullptr};
 };
 
-extern "C" int aware_version(void) { return 200; }
+extern "C" int aware_version(void) { return 300; }
 extern "C" const char* aware_last_hip_error(void) { return g_last_err.c_str(); }
 
 // ---------------------------------------------------------------------------------------------

@@ -384,6 +384,10 @@ def main():
         roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": round(peak, 1),
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None, "peak_note": peak_note,
                 "frac_of_f32_mfma_peak": round(achieved / MFMA_F32_PEAK_TF, 4),
+                "frac_of_six_product_peak": round(achieved / (MFMA_BF16_PEAK_TF / 6.0), 4),
+                "frac_note": "frac = achieved / (2.5 PFLOP/s / partial products per multiply-add of the kernel that ran); round 2's "
+                             "bf16x3 kernel ran 6 products (peak 416.7, frac 0.45-0.47), the f16 two-term kernel runs 3 (peak 833.3): "
+                             "frac_of_six_product_peak relates this run to round 2's denominator",
                 "traffic_unit": "bytes/launch", "traffic_source": None,
                 "avg_launch_us": round(ms * 1e3 / nl, 2), "launches_timed": nl,
                 "timing": "HIP events on the launch stream around every launch of 3 eager iterations (includes the eager "

@@ -55,7 +55,8 @@ typedef struct aware_detector aware_detector;
 typedef struct aware_batch aware_batch;
 typedef struct aware_embed aware_embed;
 
-/* ABI version (200: no process-global knobs; the kernel choices live in aware_embed_config) */
+/* ABI version (200: no process-global knobs, the kernel choices live in aware_embed_config; 300: conv_pipe 0 = f16 two-term
+ * kernels, optimiser / scheduler registries, device-side detector training, aware_stft_bwd for any clip length) */
 int aware_version(void);
 /* text of the last failed HIP runtime call on the calling thread (thread-local) */
 const char* aware_last_hip_error(void);
