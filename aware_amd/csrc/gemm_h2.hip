@@ -881,7 +881,9 @@ bool gemm_clip_h2_supported(int nwm, int N, int K, int lda) {
 // workgroup per CU: half the A staging per MFMA) 510 -- but no difference inside the embed loop (1.025 vs 1.026 ms per iteration,
 // alternating runs on one box); 8 x 2 (two tiles per wave, 150 VGPRs) 548; the same GEMM on v_mfma_f32_32x32x16_f16 (a wave =
 // all rows x 32 columns: half the MFMA issues, LDS fragment reads and staging per multiply-add, at the 128-VGPR limit) 565;
-// B fragments two K32 steps ahead instead of one: no change.  DESIGN.md section 4 has the counters behind this.
+// B fragments two K32 steps ahead instead of one: no change; the split arithmetic of a quarter spread behind its MFMAs (two
+// vector instructions per MFMA, sched_group_barrier) instead of ahead of them: +3 % (the scheduler then exposes the fragment
+// reads).  DESIGN.md section 4 has the counters behind this.
 int gemm_clip_h2_slab_width(int, int, int) { return 128; }
 
 // Bpk: launch_h2_pack image of Wt [N][K]; amax_in: [B][64] partial maxima of A's clips (K/16 valid per clip); amax_out: the
