@@ -282,7 +282,7 @@ def test_full_size_config3_properties(models):
 
 
 def test_full_size_config5_properties(models):
-    """BASELINE config 5 at one GPU's share (128 clips of seeded 1..10 s from 44.1 kHz, 400 iterations, a seeded chain
+    """BASELINE config 5 at one GPU's share, bench.py's own batch (256 clips of seeded 1..10 s from 44.1 kHz, 400 iterations, a seeded chain
     of 1..3 attacks per clip out of {pcm16, resample, lowpass, bandstop, cut 10 %, gaussian 20 dB}, bench.py's own
     plan): size-independent properties -- every clip's clean read-out is exact, the attacked read-out stays far from
     chance overall and exact for the chains made of benign attacks only, every clip's optimiser ran 400 steps inside
@@ -291,9 +291,9 @@ def test_full_size_config5_properties(models):
     import bench
     from aware_amd.pipeline import WatermarkPipeline, synthetic_ragged_clips
     emb, det = models
-    secs, chains = bench.config5_plan(128, 1)
+    secs, chains = bench.config5_plan(256, 1)
     assert min(secs) == 1 and max(secs) == 10 and len(set(map(tuple, chains))) > 20
-    order = sorted(range(128), key=lambda i: (-secs[i], i))
+    order = sorted(range(256), key=lambda i: (-secs[i], i))
     secs, chains = [secs[i] for i in order], [chains[i] for i in order]
     audio, bits = synthetic_ragged_clips(secs, 44100, seeds=order)
     pipe = WatermarkPipeline(emb, det, [], 16000)
@@ -308,7 +308,7 @@ def test_full_size_config5_properties(models):
     assert len(benign) >= 10 and int(wrong[benign].sum()) == 0
     key = next(k for k in pipe._sessions if not isinstance(k[0], str))
     batch, sess = pipe._sessions[key]
-    assert batch.B == 128 and max(batch.frames) == 626 and min(batch.frames) == 63
+    assert batch.B == 256 and max(batch.frames) == 626 and min(batch.frames) == 63
     assert r1.watermarked.lengths == [256 * (t - 1) for t in batch.frames]
     assert int(sess.step.cpu()[0]) == 400
     best = sess.best_loss.cpu().numpy()
