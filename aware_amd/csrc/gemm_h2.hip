@@ -2,12 +2,16 @@
 //
 // gfx950 has no fast path for f32 operands (v_mfma_f32_32x32x2_f32 runs at 1/16 of the 16-bit MFMA rate).  gemm_x3.hip
 // writes an f32 value as three bf16 terms and runs six partial products.  This file uses the other 16-bit format:
-//     a * 2^s = h + l + e,   h = RN_f16(a 2^s),  l = RN_f16(a 2^s - h),  |e| <= 2^-24 |a 2^s|
-// (binary16 has 11 significand bits: h is within 2^-12 relative, the residual a 2^s - h is exact in f32 and l rounds it to
-// within 2^-12 of itself).  The representation error e is at most HALF AN ULP of the f32 value: every operand looks as if it
-// had been rounded to f32 once more.  The product a*b is then h_a h_b + h_a l_b + l_a h_b (+ l_a l_b <= 2^-24 |ab|, dropped):
-// THREE v_mfma_f32_16x16x32_f16 with f32 accumulation per k-step, half the matrix-pipe time of the six-product kernel, 2/3 of
-// its LDS fragment traffic and weight bytes.  Each partial product is exact in f32 (22 significand bits).
+//     a * 2^s = h + l + e,   h = RN_f16(a 2^s),  l = RN_f16(a 2^s - h),  |e| <= 2^-23 |a 2^s|
+// (binary16 has 11 significand bits.  An f32 value has 24: h keeps the top 11, the residual a 2^s - h is exact in f32 -- a
+// signed integer of at most 13 bits in units of the value's last place -- and l keeps 11 bits and the sign of it: exact for
+// three quarters of all values, off by ONE unit in the last place of the f32 value for the rest; measured rms 2^-24.5).  The product a*b
+// is h_a h_b + h_a l_b + l_a h_b, the term l_a l_b (<= 2^-22 |ab|, rms 2^-24.6) is dropped: THREE v_mfma_f32_16x16x32_f16
+// with f32 accumulation per k-step, half the matrix-pipe time of the six-product kernel, 2/3 of its LDS fragment traffic and
+// weight bytes.  Each partial product is exact in f32 (22 significand bits).  Error of one product against the exact a*b:
+// rms 2^-23.7, worst case 2^-21 (an f32 multiply: rms 2^-25.2, worst 2^-24) -- i.e. this pipe is NOT bit-for-bit f32
+// arithmetic; what it keeps is the error LEVEL of an f32 dot product, which the f32 accumulation of K terms sets in both
+// cases (measured below).  The exact alternative is gemm_x3.hip (conv_pipe 2).
 //
 // binary16's exponent range (normal down to 2^-14) makes the scale 2^s part of the format:
 //   * weights: one power of two per output channel (row of Wt), chosen when the weights are packed so that the row's

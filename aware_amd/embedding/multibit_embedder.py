@@ -43,6 +43,7 @@ class AWAREEmbedder(BaseEmbedder):
         self._sched = get_scheduler(self.scheduler_name, self._opt, num_iterations, **self.scheduler_params)
         self.verbose = verbose
         self.use_graph = use_graph
+        self.conv_pipe = "f16x2"                       # runtime.CONV_PIPES: arithmetic of the detector's conv-block GEMMs
         self.audio_preprocess_pipeline = [WaveformNormalizer(), STFT(frame_length, hop_length, window, win_length), STFTDecomposer()]
         self.audio_postprocess_pipeline = [STFTAssembler(), ISTFT(frame_length, hop_length, window, win_length), WaveformNormalizer()]
 
@@ -61,7 +62,7 @@ class AWAREEmbedder(BaseEmbedder):
     def start_session(self, batch: "rt.Batch", sample_rate: int) -> "rt.EmbedSession":
         plan = self._plan(sample_rate)
         common = dict(num_iterations=self.num_iterations, tolerance_db=self.tolerance_db, loss=self.loss.name,
-                      use_graph=self.use_graph, l1_weight=getattr(self.loss, "l1_weight", 0.0))
+                      use_graph=self.use_graph, l1_weight=getattr(self.loss, "l1_weight", 0.0), conv_pipe=self.conv_pipe)
         det = self.detection_net.device_weights(plan)
         if is_card_default(self._opt) and self._sched["constant_lr"]:
             # the model card's configuration (NAdam, a scheduler that cannot fire): fused in the adjoint kernel's epilogue

@@ -215,6 +215,26 @@ def run_stub(args, rank, world):
     parallel.barrier()
     wall = time.perf_counter() - t0
     sums, maxes = parallel.reduce_metrics({"seconds": 3.0 * args.steps, "ranks": 1}, {"wall": wall}, device="cpu")
+    # ---- the same workload on the EXACT pipe (three bf16 terms, six products), one step on rank 0 at N = 1: the rate a reader
+    # who does not accept the two-term split as f32 arithmetic should take ----
+    exact = None
+    if world == 1 and args.conv_pipe == "f16x2" and not args.no_profile:
+        embedder.conv_pipe = "bf16x3"
+        pipe2 = WatermarkPipeline(embedder, detector, pipe.attacks, sample_rate=16000, attack_mode=pipe.attack_mode)
+        pipe2.prepare(n16, input_rate=44100)
+        pipe2.run(audio, bits, **run_kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r2 = pipe2.run(audio, bits, **run_kw)
+        e2 = int(r2.bit_errors)
+        torch.cuda.synchronize()
+        w2 = time.perf_counter() - t0
+        exact = {"conv_pipe": "bf16x3", "value": round(r2.seconds / w2, 2), "unit": "waveform-seconds/sec", "steps": 1,
+                 "ms_per_step": round(w2 * 1e3, 2), "ber_percent": round(100.0 * e2 / (len(n16) * 20), 4),
+                 "note": "same workload, conv blocks on gemm_x3.hip (every f32 operand split exactly into three bf16 terms, six "
+                         "partial products, f32 accumulation): bit-level f32 operands"}
+        embedder.conv_pipe = args.conv_pipe
+        del pipe2
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
@@ -223,6 +243,18 @@ def run_stub(args, rank, world):
                           "n_gpus": world, "ranks_seen": int(sums["ranks"]), "steps": args.steps, "warmup": args.warmup,
                           "config": {"workload": "stub"}}))
     return 0
+
+
+DTYPE_NOTE = {
+    "f16x2": "f32 accumulation on the 16-bit MFMA pipe; conv-block GEMMs: every f32 operand scaled by a power of two and carried as TWO "
+             "binary16 terms (within one f32 ulp of the operand, rms 2^-24.5), 3 partial products, the l_a*l_b term (<= 2^-22) dropped "
+             "-- gemm_h2.hip: error level of an f32 dot product (against fp64 at or below the f32-input MFMA kernel's on every "
+             "tested shape), not bit-for-bit f32 operands; mel / read-out / small grids: three bf16 terms, exact, 6 products -- "
+             "gemm_x3.hip.  exact_pipe = the same workload with the conv blocks on the exact split",
+    "bf16x3": "f32 (every detector GEMM on the bf16 MFMA pipe with each f32 operand split exactly into three bf16 terms, 6 partial "
+              "products, f32 accumulation -- gemm_x3.hip)",
+    "f32": "f32 (f32-input MFMA)",
+}
 
 
 def main():
@@ -235,6 +267,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=3.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--conv-pipe", default="f16x2", choices=("f16x2", "bf16x3", "f32"),
+                    help="arithmetic of the conv-block GEMMs (aware_amd.runtime.CONV_PIPES); the default also times bf16x3 beside it")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass (roofline = null)")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -270,6 +304,7 @@ def main():
         from aware_amd.embedding.losses import get_loss_fn
         embedder.loss = get_loss_fn("push_extremes_l1", l1_weight=0.05)
     embedder.use_graph = not args.no_graph
+    embedder.conv_pipe = args.conv_pipe
     run_kw = {"input_rate": 44100}
     if wl == "config5":
         secs_all, chains_all = config5_plan(per_gpu, world)
@@ -348,7 +383,7 @@ def main():
         uniform = len(set(batch.frames)) == 1 and batch.frames[0] // 2 <= 128
         # capi.hip (kH2MinGrid, clip_tile_groups, h2_rag): uniform batches from 32 clips on and every ragged batch run their
         # conv blocks on the f16 two-term kernels; smaller uniform batches on the bf16x3 latency kernel
-        on_h2 = "gemm_x3_fwd" in breakdown and (not uniform or len(batch.frames) >= 32)
+        on_h2 = args.conv_pipe == "f16x2" and "gemm_x3_fwd" in breakdown and (not uniform or len(batch.frames) >= 32)
         if on_h2:
             peak = MFMA_BF16_PEAK_TF / 3.0
             peak_note = ("f32-equivalent peak of the f16 two-term kernel (gemm_h2.hip): dense f16 MFMA peak (2.5 PFLOP/s, the bf16 "
@@ -364,7 +399,9 @@ def main():
             fl = 2.0 * rows * (ch[0] * ch[1] + ch[1] * ch[2] + ch[2] * ch[3]) + 2.0 * rows * (ch[3] * ch[2] + ch[2] * ch[1])
             ms = breakdown["gemm_x3_fwd"][0] + breakdown["gemm_x3_bwd"][0]
             nl = breakdown["gemm_x3_fwd"][1] + breakdown["gemm_x3_bwd"][1]
-            kname = ("gemm_clip_h2_kernel" if uniform else "gemm_ragged_h2_kernel") if on_h2 else "gemm_clip_x3_small_kernel"
+            big = not uniform or len(batch.frames) >= 32
+            kname = (("gemm_clip_h2_kernel" if uniform else "gemm_ragged_h2_kernel") if on_h2 else
+                     ("gemm_clip_x3_kernel" if uniform else "gemm_ragged_x3_kernel") if big else "gemm_clip_x3_small_kernel")
             name = f"aware::{kname} (forward epilogue x3, backward epilogue x2 per iteration)"
             if not uniform:
                 # the last conv's data gradient of a ragged batch is one more launch of this kind (readout_grad_ragged_x3_kernel,
@@ -409,6 +446,26 @@ def main():
             wb = 4.0 if on_h2 else 6.0
             alg = sum(4.0 * rows * (k + n) + wb * k * n for k, n in pairs) + 4.0 * rows * (ch[2] + ch[1])
             roof["algorithmic_bytes_per_launch"] = round(alg / 5)
+    # ---- the same workload on the EXACT pipe (three bf16 terms, six products), one step on rank 0 at N = 1: the rate a reader
+    # who does not accept the two-term split as f32 arithmetic should take ----
+    exact = None
+    if world == 1 and args.conv_pipe == "f16x2" and not args.no_profile:
+        embedder.conv_pipe = "bf16x3"
+        pipe2 = WatermarkPipeline(embedder, detector, pipe.attacks, sample_rate=16000, attack_mode=pipe.attack_mode)
+        pipe2.prepare(n16, input_rate=44100)
+        pipe2.run(audio, bits, **run_kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r2 = pipe2.run(audio, bits, **run_kw)
+        e2 = int(r2.bit_errors)
+        torch.cuda.synchronize()
+        w2 = time.perf_counter() - t0
+        exact = {"conv_pipe": "bf16x3", "value": round(r2.seconds / w2, 2), "unit": "waveform-seconds/sec", "steps": 1,
+                 "ms_per_step": round(w2 * 1e3, 2), "ber_percent": round(100.0 * e2 / (len(n16) * 20), 4),
+                 "note": "same workload, conv blocks on gemm_x3.hip (every f32 operand split exactly into three bf16 terms, six "
+                         "partial products, f32 accumulation): bit-level f32 operands"}
+        embedder.conv_pipe = args.conv_pipe
+        del pipe2
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         parallel.barrier()
@@ -421,10 +478,7 @@ def main():
         "value": round(value, 2), "unit": "waveform-seconds/sec", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(maxes["wall"] / args.steps * 1e3, 2), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 (conv-block GEMMs on the 16-bit MFMA pipe with f32 accumulation and every f32 operand carried by a multi-term "
-                 "split: two binary16 terms after a power-of-two scaling, representation error <= half an f32 ulp, 3 partial "
-                 "products -- gemm_h2.hip; small grids / ragged batches / mel / read-out: three bf16 terms, exact, 6 products -- "
-                 "gemm_x3.hip.  Error against fp64 at or below the f32-input MFMA kernel's on every tested shape)",
+        "dtype": DTYPE_NOTE[args.conv_pipe],
         "data": "synthetic",
         "config": {"workload": desc, "clips_per_gpu": len(n16), "clip_seconds": clip_seconds,
                    "iterations": embedder.num_iterations,
@@ -432,6 +486,7 @@ def main():
         "ber_percent": round(100.0 * sums["bit_errors"] / sums["bits"], 4),
         "ber_percent_clean": round(100.0 * sums["clean_bit_errors"] / sums["bits"], 4),
         "roofline": roof,
+        "exact_pipe": exact,
         "kernel_ms_per_iteration": {k: round(v[0] / 3, 4) for k, v in breakdown.items()},
         "kernel_ms_per_iteration_note": "eager launches, HIP-event timed (each figure includes the 2-5 us eager inter-kernel gap; "
                                         "their sum therefore exceeds ms_per_step / iterations, which runs from hipGraphs)",

@@ -205,7 +205,7 @@ typedef struct aware_embed_config {
     /* kernel choices of this session (zero = default).
      * conv_pipe 0: the conv blocks and their data-gradient GEMMs of a uniform batch that fills the chip run on the f16 matrix
      *   pipe: every f32 operand scaled by a power of two (per output channel / per clip) and written as two binary16 terms
-     *   (representation error <= half an f32 ulp), three partial products per multiply-add, f32 accumulation
+     *   (representation error <= one f32 ulp, rms 2^-24.5; l_a l_b dropped), three partial products per multiply-add, f32 accumulation
      *   (csrc/gemm_h2.hip); every other GEMM as conv_pipe 2.
      * conv_pipe 2: the detector's GEMMs on the bf16 matrix pipe with every f32 operand split exactly into three
      *   bf16 terms, six partial products per multiply-add, f32 accumulation (csrc/gemm_x3.hip) wherever K % 64 == 0 and
@@ -385,7 +385,7 @@ int aware_gemm_clip_last(const float* A, int lda, const void* Bpk, const float* 
                          int N, int K, float* rstd_out, const void* lastpk, float* zpart, int CL, void* stream);
 /* The same block on the DEFAULT conv pipe of the embed loop (csrc/gemm_h2.hip): the f16 matrix pipe with every f32 operand
  * written as two binary16 terms after a power-of-two scaling (per output channel for the weights, per clip for A), three
- * partial products per multiply-add, f32 accumulation; representation error <= 2^-24 relative per operand (half an f32 ulp).
+ * partial products per multiply-add, f32 accumulation; representation error <= 2^-23 relative per operand (one f32 ulp; rms 2^-24.5), the l_a l_b term (<= 2^-22) dropped.
  * Bt: DEV [N][K] (row pitch ldb); the entry packs it and computes the clips' max |A| into `workspace`
  * (>= aware_gemm_clip_h2_workspace_bytes).  epi 0..2 as aware_gemm_clip; lastpk / zpart / CL: as aware_gemm_clip_last (epi 1,
  * may be NULL / 0); amax_out: dev [B][64] partial maxima of |C| per clip (N/16 written per clip) or NULL.

@@ -256,3 +256,31 @@ def test_aware_alias_package():
     assert detect_watermark is aware_amd.service.detect_watermark
     emb, det = load()
     assert type(emb).__name__ == "AWAREEmbedder" and PatternEncoder().mode == "bits2bipolar"
+
+
+def test_two_term_binary16_split_error_model():
+    """The numbers csrc/gemm_h2.hip, DESIGN.md and bench.py's `dtype` text state for the f16 two-term operand split, restated in
+    numpy: h = RN_f16(x), l = RN_f16(x - h) after scaling the maximum into [2^13, 2^14).  Representation error <= one f32 ulp
+    (2^-23 relative), exact for three quarters of all values; the three-product a*b (l_a*l_b dropped) is within 2^-21 of the exact
+    product, rms about 2^-23.7 -- NOT bit-level f32, which is why the exact bf16x3 pipe stays selectable."""
+    rng = np.random.default_rng(5)
+
+    def split(x):
+        h = x.astype(np.float16)
+        l = (x - h.astype(np.float32)).astype(np.float16)
+        return h.astype(np.float64), l.astype(np.float64)
+
+    a = (rng.uniform(1, 2, 1_000_000) * 2.0 ** 13).astype(np.float32)
+    b = (rng.uniform(1, 2, 1_000_000) * 2.0 ** 13).astype(np.float32)
+    ha, la = split(a)
+    hb, lb = split(b)
+    rep = np.abs(a.astype(np.float64) - ha - la) / a
+    assert rep.max() <= 2.0 ** -23 and 0.7 < np.mean(rep == 0) < 0.8
+    assert 2.0 ** -25 < np.sqrt(np.mean(rep ** 2)) < 2.0 ** -24
+    exact = a.astype(np.float64) * b.astype(np.float64)
+    err = np.abs(ha * hb + ha * lb + la * hb - exact) / exact
+    assert err.max() <= 2.0 ** -21 and 2.0 ** -24.2 < np.sqrt(np.mean(err ** 2)) < 2.0 ** -23.3
+    assert (np.abs(la * lb) / exact).max() <= 2.0 ** -22
+    # each of the three partial products fits f32 exactly (22 significand bits): the MFMA's f32 accumulation adds no product rounding
+    for p in (ha * hb, ha * lb, la * hb):
+        assert np.array_equal(p, p.astype(np.float32).astype(np.float64))
