@@ -13,7 +13,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AWARE_HIP_LIB") or os.path.join(_HERE, "libaware_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["capi.hip", "dsp_kernels.hip", "dsp_stream.hip", "seam_kernels.hip", "detector_kernels.hip", "gemm_x3.hip", "gemm_h2.hip", "gemm_h2p.hip", "attack_kernels.hip"]
+SOURCES = ["capi.hip", "dsp_kernels.hip", "dsp_stream.hip", "seam_kernels.hip", "detector_kernels.hip", "gemm_x3.hip", "gemm_h2.hip", "attack_kernels.hip"]
 
 AWARE_OK = 0
 ERRORS = {-1: "bad argument", -2: "unsupported configuration", -3: "HIP runtime error", -4: "workspace too small"}
@@ -142,8 +142,6 @@ SIGNATURES = {
     "aware_gemm_clip": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "aware_gemm_clip_last": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "aware_gemm_clip_h2_workspace_bytes": (_sz, [_i, _i, _i]),
-    "aware_gemm_clip_h2p_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "aware_gemm_clip_h2p": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "aware_gemm_clip_h2": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "aware_gemm_nt": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
 }

@@ -1723,59 +1723,6 @@ extern "C" int aware_gemm_clip_h2(const float* A, int lda, const float* Bt, int 
     return AWARE_OK;
 }
 
-// The same block on the PRE-SPLIT form of the default pipe (csrc/gemm_h2p.hip): operands travel between the layers as binary16
-// (h, l) fragment images ("planes") with one power-of-two scale per (clip, 128-column slab).  Test / roofline entry: converts
-// the f32 operands the caller hands over into planes where the configuration asks for them, runs the kernel, converts a planes
-// result back to f32 rows.  a_planes 0: A read as f32 rows and split on the fly (epi 1 without lastpk only); out_planes 1: the
-// kernel writes planes (C = their f32 reading).  epi 0..2 as aware_gemm_clip_h2; epi 1 with lastpk / zpart: the forward block
-// in front of the skinny last conv (needs a_planes 1, out_planes 0).  epi 2: `act` (f32 rows [B*32*ceil(Tp/32)][N]) is handed
-// to the kernel as planes.  sout: dev [B][8] slab scales of the planes result or NULL.  N % 128 == 0, K % 128 == 0, K <= 1024.
-extern "C" size_t aware_gemm_clip_h2p_workspace_bytes(int B, int Tp, int N, int K) {
-    if (B < 1 || Tp < 1 || N < 1 || K < 1) return 0;
-    const int nwm = (Tp + 31) / 32;
-    return h2_packed_bytes(N, K) + h2p_planes_bytes(B, nwm, K) + 2 * h2p_planes_bytes(B, nwm, N) + (size_t)B * (64 + 8 * 3) * sizeof(float) +
-           4096;
-}
-extern "C" int aware_gemm_clip_h2p(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc, int B,
-                                   int Tp, int N, int K, int epi, float* rstd_io, const float* act, const void* lastpk, float* zpart,
-                                   int CL, int a_planes, int out_planes, float* sout, void* workspace, size_t workspace_bytes,
-                                   void* stream) {
-    if (!A || !Bt || !C || !workspace || B < 1 || Tp < 1 || Tp > 128 || epi < 0 || epi > 2 || (ldb & 3) || (lda & 3) || (ldc & 3))
-        return AWARE_E_BADARG;
-    if (epi != 0 && !rstd_io) return AWARE_E_BADARG;
-    if (epi == 2 && !act) return AWARE_E_BADARG;
-    const bool last = epi == 1 && lastpk && zpart;
-    if (!a_planes && (epi != 1 || last)) return AWARE_E_BADARG;
-    if (last && out_planes) return AWARE_E_BADARG;
-    const int nwm = (Tp + 31) / 32;
-    if (!gemm_clip_h2p_supported(nwm, N, K)) return AWARE_E_BADARG;
-    if (workspace_bytes < aware_gemm_clip_h2p_workspace_bytes(B, Tp, N, K)) return AWARE_E_WORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
-    Carver c(workspace, workspace_bytes);
-    void* pk = c.take<char>(h2_packed_bytes(N, K));
-    void* pa = c.take<char>(h2p_planes_bytes(B, nwm, K));
-    void* pact = c.take<char>(h2p_planes_bytes(B, nwm, N));
-    void* pout = c.take<char>(h2p_planes_bytes(B, nwm, N));
-    float* amax = c.take<float>((size_t)B * 64);
-    float* sa = c.take<float>((size_t)B * 8);
-    float* sact = c.take<float>((size_t)B * 8);
-    float* so = c.take<float>((size_t)B * 8);
-    if (!c.ok) return AWARE_E_WORKSPACE;
-    launch_h2_pack(Bt, ldb, N, K, pk, st, true);
-    if (a_planes) launch_h2p_from_f32(A, lda, K, B, nwm, pa, sa, st);
-    else launch_clip_amax(A, lda, K, 32 * nwm, B, amax, st);
-    if (epi == 2) launch_h2p_from_f32(act, ldc, N, B, nwm, pact, sact, st);
-    launch_gemm_clip_h2p(a_planes ? (const void*)pa : (const void*)A, lda, a_planes ? sa : amax, a_planes != 0, pk, bias,
-                         out_planes ? nullptr : C, ldc, out_planes ? pout : nullptr, so, B, nwm, Tp, N, K, epi, rstd_io, pact, sact, st,
-                         last ? lastpk : nullptr, zpart, CL);
-    if (out_planes) {
-        launch_h2p_to_f32(pout, so, N, B, nwm, C, ldc, st);
-        if (sout) HIPCHK(hipMemcpyAsync(sout, so, (size_t)B * 8 * sizeof(float), hipMemcpyDeviceToDevice, st));
-    }
-    LAUNCHCHK();
-    return AWARE_OK;
-}
-
 extern "C" int aware_gemm_nt(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc,
                              int M, int N, int K, void* stream) {
     if (!A || !Bt || !C || M < 1 || N < 1 || K < 4 || (K & 3) || (lda & 3) || (ldb & 3)) return AWARE_E_BADARG;

@@ -131,8 +131,7 @@ void launch_gemm_clip_x3(const float* A, int lda, const void* Bpk, const float* 
                          const void* lastpk = nullptr, float* zpart = nullptr, int CL = 0, int Mrows = 0);
 // ---- gemm_h2.hip: the same block on the f16 matrix pipe, two-term operand split, three products (f32-level) ----
 size_t h2_packed_bytes(int N, int K);
-void launch_h2_pack(const float* Wt_dev, int ldw, int N, int K, void* out, hipStream_t st, bool perm = false);   // device -> device
-const float* h2_inv_scale(const void* packed, int N, int K);
+void launch_h2_pack(const float* Wt_dev, int ldw, int N, int K, void* out, hipStream_t st);   // device -> device
 void launch_clip_amax(const float* A, int lda, int K, int rows_per_clip, int B, float* amax, hipStream_t st);
 bool gemm_clip_h2_supported(int nwm, int N, int K, int lda);
 int gemm_clip_h2_slab_width(int nwm, int N, int B);     // columns per workgroup (FWD_LAST: N / width partial slabs in zpart)
@@ -144,16 +143,6 @@ void launch_gemm_ragged_h2(const float* A, int lda, const void* Bpk, const float
                            float* C, int ldc, int B, const int* frame_off, const int* pool_off, const int* order, int N, int K,
                            int epi, float* rstd_io, const float* act, hipStream_t st);
 void launch_ragged_amax(const float* A, int lda, int K, const int* frame_off, const int* pool_off, int B, float* amax, hipStream_t st);
-// ---- gemm_h2p.hip: the uniform-batch chain with the operands PRE-SPLIT between the layers ("planes": per clip the A-fragment
-// images [K/32][2][2 nwm][64][16 B] of the consuming GEMM + one power-of-two scale per 128-column slab, [B][8]) ----
-bool gemm_clip_h2p_supported(int nwm, int N, int K);
-size_t h2p_planes_bytes(int B, int nwm, int K);            // == B * 32 nwm * K * 4: planes fit the f32 rows they replace
-void launch_h2p_from_f32(const float* A, int lda, int K, int B, int nwm, void* P, float* pscale, hipStream_t st);
-void launch_h2p_to_f32(const void* P, const float* pscale, int K, int B, int nwm, float* C, int ldc, hipStream_t st);
-void launch_gemm_clip_h2p(const void* A, int lda, const float* sin, bool a_planes, const void* Bpk, const float* bias, float* Cf,
-                          int ldc, void* Pout, float* sout, int B, int nwm, int Tp, int N, int K, int epi, float* rstd_io,
-                          const void* actP, const float* sact, hipStream_t st, const void* lastpk = nullptr, float* zpart = nullptr,
-                          int CL = 0);
 // (Mrows > 0, plain epilogue only: the matrices have Mrows < B*32*nwm rows -- the last row block is partial)
 // the same block for ragged batches / clips of any length (one launch; clips longer than 96 pooled frames in two passes)
 void launch_gemm_ragged_x3(const float* A, int lda, const void* Bpk, const float* bias, float* C, int ldc, int B,

@@ -549,36 +549,6 @@ def gemm_clip_h2(a: torch.Tensor, bt: torch.Tensor, bias, B: int, Tp: int, epi: 
     return (c, rstd, amax) if w_last is None else (c, rstd, amax, zpart)
 
 
-def gemm_clip_h2p(a: torch.Tensor, bt: torch.Tensor, bias, B: int, Tp: int, epi: int = 0, rstd=None, act=None, w_last=None,
-                  a_planes: bool = True, out_planes: bool = True):
-    """One clip-aligned conv block on the pre-split ("planes") form of the f16 two-term pipe (aware_gemm_clip_h2p, csrc/gemm_h2p.hip:
-    the kernels the embed loop of a uniform batch runs).  Returns (C, rstd, slab_scales[B, 8]) and, with w_last [CL, N]
-    (epi 1, a_planes, not out_planes), also zpart [N/128, M, CL]."""
-    lib = load_library()
-    M, K = a.shape
-    N = bt.shape[0]
-    dev = a.device
-    btd = bt.to(dev).contiguous()
-    c = torch.empty((M, N), dtype=torch.float32, device=dev)
-    if rstd is None:
-        rstd = torch.zeros((B, N), dtype=torch.float32, device=dev)
-    sout = torch.zeros((B, 8), dtype=torch.float32, device=dev)
-    nbytes = int(lib.aware_gemm_clip_h2p_workspace_bytes(B, Tp, N, K))
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    pkl, zpart, CL = None, None, 0
-    if w_last is not None:
-        CL = w_last.shape[0]
-        wl = torch.zeros((16 * ((CL + 15) // 16), N), dtype=torch.float32)
-        wl[:CL] = w_last.detach().cpu().float()
-        pkl = x3_pack(wl)
-        zpart = torch.zeros((N // 128, M, CL), dtype=torch.float32, device=dev)
-    check(lib.aware_gemm_clip_h2p(_ptr(a), a.stride(0), _ptr(btd), btd.stride(0), _ptr(bias), _ptr(c), N, B, Tp, N, K, epi, _ptr(rstd),
-                                  _ptr(act), _ptr(pkl), _ptr(zpart), CL, int(a_planes), int(out_planes), _ptr(sout), _ptr(ws), nbytes,
-                                  _stream()), "aware_gemm_clip_h2p")
-    torch.cuda.current_stream().synchronize()
-    return (c, rstd, sout) if w_last is None else (c, rstd, sout, zpart)
-
-
 def gemm_clip_last(a: torch.Tensor, bt: torch.Tensor, bias, w_last: torch.Tensor, B: int, Tp: int):
     """The forward conv block + split-K partials of the next (skinny) conv, as the embed loop runs block 2
     (aware_gemm_clip_last).  a: [B*32*ceil(Tp/32), K]; bt: [N, K]; w_last: [CL, N].  Returns (C, rstd, zpart[N/128, M, CL])."""

@@ -395,20 +395,6 @@ int aware_gemm_clip_h2(const float* A, int lda, const float* Bt, int ldb, const 
                        int N, int K, int epi, float* rstd_io, const float* act, const void* lastpk, float* zpart, int CL,
                        float* amax_out, void* workspace, size_t workspace_bytes, void* stream);
 
-/* The same block on the PRE-SPLIT form of the default pipe (csrc/gemm_h2p.hip), the one the embed loop of a uniform batch runs:
- * between the layers an operand travels as binary16 (h, l) A-fragment images of the consuming GEMM ("planes": per clip
- * [K/32][2][2*ceil(Tp/32)][64 lanes][16 bytes] -- the bytes of the f32 rows they replace) with one power-of-two scale per
- * (clip, 128-column slab); the producer's epilogue writes them straight from its accumulators (weights-first MFMA: a lane
- * holds four consecutive channels of one row), the consumer stages them with LDS-DMA loads and never splits.
- * Test / roofline entry over f32 operands: converts A (a_planes 1) and `act` (epi 2) to planes, runs the kernel, converts a
- * planes result (out_planes 1) back to f32 rows in C.  a_planes 0 (A split on the fly) is valid for epi 1 without lastpk;
- * lastpk / zpart / CL (epi 1): as aware_gemm_clip_last, needs a_planes 1 and out_planes 0.  sout: dev [B][8] slab scales of
- * the planes result or NULL.  Bt: DEV [N][K].  N % 128 == 0, K % 128 == 0, K <= 1024, Tp <= 128; lda, ldb, ldc % 4 == 0. */
-size_t aware_gemm_clip_h2p_workspace_bytes(int B, int Tp, int N, int K);
-int aware_gemm_clip_h2p(const float* A, int lda, const float* Bt, int ldb, const float* bias, float* C, int ldc, int B, int Tp,
-                        int N, int K, int epi, float* rstd_io, const float* act, const void* lastpk, float* zpart, int CL,
-                        int a_planes, int out_planes, float* sout, void* workspace, size_t workspace_bytes, void* stream);
-
 #ifdef __cplusplus
 }
 #endif
