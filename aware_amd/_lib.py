@@ -63,7 +63,7 @@ class EmbedConfig(C.Structure):
     _fields_ = [("num_iterations", C.c_int), ("tolerance_db", C.c_float), ("loss", C.c_int),
                 ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("momentum_decay", C.c_float), ("use_graph", C.c_int), ("conv_pipe", C.c_int), ("readout", C.c_int),
-                ("dsp_path", C.c_int), ("l1_weight", C.c_float)]
+                ("dsp_path", C.c_int), ("l1_weight", C.c_float), ("mel", C.c_int)]
 
 
 class OptimizerConfig(C.Structure):

@@ -101,6 +101,15 @@ struct aware_detector {
     void* wTh2[8] = {nullptr};
     void* h2mem = nullptr;
     float* bias[8] = {nullptr};
+    // the mel filter bank as two taps per band column (a triangular bank has at most two adjacent non-zero weights per bin):
+    // melw [kFS] float2, melm [kFS] first tap's mel index (<= 126); null when the basis handed over is not of that form
+    void* mel2mem = nullptr;
+    float2* melw = nullptr;
+    unsigned char* melm = nullptr;
+    // ... and per filter as a short run of adjacent band columns (forward): melf_w [n_mels][kMelTapsB], melf_s [n_mels]; null
+    // when a filter's support is longer than the folded analysis kernel takes (kMelTapsA / kMelTapsB columns)
+    float* melf_w = nullptr;
+    unsigned char* melf_s = nullptr;
 };
 
 extern "C" int aware_version(void) { return 300; }
@@ -442,6 +451,56 @@ static int detector_upload(aware_detector* d, const float* mel_basis, const floa
             h[o_melT + (size_t)j * kFS + f] = v;
             h[o_melB + (size_t)f * n_mels + j] = v;
         }
+    {
+        // two-tap form of the band's columns, if the basis has it (any triangular filter bank does)
+        std::vector<float2> tw(kFS, make_float2(0.f, 0.f));
+        std::vector<unsigned char> tm(kFS, 0);
+        bool sparse = n_mels == 128;
+        for (int f = 0; f < nb && sparse; ++f) {
+            int first = -1, count = 0, lastnz = -1;
+            for (int j = 0; j < n_mels; ++j)
+                if (h[o_melB + (size_t)f * n_mels + j] != 0.f) { if (first < 0) first = j; lastnz = j; ++count; }
+            if (count == 0) continue;
+            if (count > 2 || lastnz - first > 1) { sparse = false; break; }
+            const int m1 = first < n_mels - 1 ? first : n_mels - 2;
+            tm[f] = (unsigned char)m1;
+            tw[f] = make_float2(h[o_melB + (size_t)f * n_mels + m1], h[o_melB + (size_t)f * n_mels + m1 + 1]);
+        }
+        // forward: filter m as kMelTapsA (m < 64) / kMelTapsB adjacent columns starting at fs[m]
+        std::vector<float> fw((size_t)128 * kMelTapsB, 0.f);
+        std::vector<unsigned char> fs(128, 0);
+        bool runs = sparse;
+        for (int m = 0; m < n_mels && runs; ++m) {
+            int first = -1, lastnz = -1;
+            for (int f = 0; f < nb; ++f)
+                if (h[o_melT + (size_t)m * kFS + f] != 0.f) { if (first < 0) first = f; lastnz = f; }
+            if (first < 0) continue;
+            const int taps = m < 64 ? kMelTapsA : kMelTapsB;
+            const int start = first <= kFS - kMelTapsB ? first : kFS - kMelTapsB;
+            if (lastnz - start >= taps) { runs = false; break; }
+            fs[m] = (unsigned char)start;
+            for (int j = 0; j < taps; ++j) fw[(size_t)m * kMelTapsB + j] = h[o_melT + (size_t)m * kFS + start + j];
+        }
+        if (sparse) {
+            const size_t bytes = kFS * (sizeof(float2) + 1) + 128 * (kMelTapsB * sizeof(float) + 1) + 64;
+            if (!d->mel2mem) HIPCHK(hipMalloc(&d->mel2mem, bytes));
+            char* base = (char*)d->mel2mem;
+            d->melw = (float2*)base;
+            d->melf_w = (float*)(base + kFS * sizeof(float2));
+            d->melm = (unsigned char*)(base + kFS * sizeof(float2) + 128 * kMelTapsB * sizeof(float));
+            d->melf_s = d->melm + kFS;
+            HIPCHK(hipMemcpy(d->melw, tw.data(), kFS * sizeof(float2), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(d->melm, tm.data(), kFS, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(d->melf_w, fw.data(), fw.size() * sizeof(float), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(d->melf_s, fs.data(), 128, hipMemcpyHostToDevice));
+            if (!runs) { d->melf_w = nullptr; d->melf_s = nullptr; }
+        } else {
+            d->melw = nullptr;
+            d->melm = nullptr;
+            d->melf_w = nullptr;
+            d->melf_s = nullptr;
+        }
+    }
     size_t o_w[8], o_wT[8], o_b[8];
     for (int l = 0; l < n_layers; ++l) {
         const int ci = channels[l], co = channels[l + 1];
@@ -591,6 +650,7 @@ extern "C" void aware_detector_destroy(aware_detector* d) {
     if (d->mem) (void)hipFree(d->mem);
     if (d->pkmem) (void)hipFree(d->pkmem);
     if (d->h2mem) (void)hipFree(d->h2mem);
+    if (d->mel2mem) (void)hipFree(d->mel2mem);
     delete d;
 }
 
@@ -680,8 +740,9 @@ static bool mel_front_applies(const aware_detector* d, const aware_batch* b, int
 }
 
 // forward through the network; mag [NF][256] -> act[last], pred
+// xm_ready: o.xm already holds the raw mel tile (the analysis kernel wrote it: mel projection folded in); mag is not read
 static int det_forward(const aware_detector* d, const aware_batch* b, const float* mag, DetBufs& o, hipStream_t st,
-                       int pipe = 0, bool skip_last = false) {
+                       int pipe = 0, bool skip_last = false, bool xm_ready = false) {
     // conv blocks of a uniform batch that fills the chip: the f16 two-term kernel (default pipe); its per-clip scale comes
     // from partial maxima that the producer of each operand leaves behind (x0_max: whether o.amax[0] is current)
     const int nwm0 = clip_tile_groups(b);
@@ -694,7 +755,11 @@ static int det_forward(const aware_detector* d, const aware_batch* b, const floa
                !(l == d->n_layers - 1 && d->ch[l + 1] <= 64);
     };
     bool cur_max = false;            // o.amax[l] holds the maxima of the current layer input
-    if (mel_front_applies(d, b, pipe)) {
+    if (xm_ready) {
+        cur_max = launch_mel_norm_fwd(o.xm, b->d_frame_off, b->d_pool_off, o.x0, o.mstats, o.gstat, o.mpart, o.mstride, b->B,
+                                      b->max_frames, st, (pipe == 0 && clip_tile_groups(b)) ? o.amax[0] : nullptr);
+        LAUNCHCHK(); PROF(K_MELNORM);
+    } else if (mel_front_applies(d, b, pipe)) {
         // uniform batch that fills the chip with one workgroup per clip: the whole mel block in one launch
         launch_mel_front_x3(mag, kFS, d->melTpk, b->d_frame_off, b->d_pool_off, o.xm, o.x0, o.mstats, o.gstat, b->B, b->T[0],
                             kFS, st, o.amax[0]);
@@ -837,6 +902,10 @@ struct DetGradCtx {
     float* const* wgrad = nullptr;
     float* const* bgrad = nullptr;
     float *tr1 = nullptr, *tr2 = nullptr;
+    // the caller expands dL/d(mel) (left in DetBufs::xm) to dL/d|S| itself (streaming synthesis adjoint, two taps per bin):
+    // the K = 128 GEMM into gmag is skipped
+    bool mel_grad_only = false;
+    bool xm_ready = false;            // DetBufs::xm holds the raw mel tile on entry (det_forward)
 };
 static int det_forward_backward(const aware_detector* d, const aware_batch* b, const float* mag, DetBufs& db,
                                 const DetGradCtx& G, hipStream_t st) {
@@ -848,7 +917,7 @@ static int det_forward_backward(const aware_detector* d, const aware_batch* b, c
     const bool fused_readout = G.readout == 0 && !G.wgrad && pipe != 1 && nwm && nl >= 2 && d->lastpk && G.target &&
                                readout_x3_supported(nwm, d->ch[nl - 1], d->ch[nl]) && d->wpk[nl - 2] &&
                                gemm_clip_x3_supported(nwm, d->ch[nl - 1], d->ch[nl - 2], d->ch[nl - 2]);
-    int rc = det_forward(d, b, mag, db, st, pipe, fused_readout);
+    int rc = det_forward(d, b, mag, db, st, pipe, fused_readout, G.xm_ready);
     if (rc) return rc;
     float* dA = G.d1;
     float* dB = G.d2;
@@ -975,8 +1044,10 @@ static int det_forward_backward(const aware_detector* d, const aware_batch* b, c
                             b->max_frames, st);
         LAUNCHCHK(); PROF(K_MELNORM);
     }
-    gemm_plain(pipe, db.xm, 128, d->melB, 128, d->melBpk, nullptr, G.gmag, kFS, b->NF, kFS, 128, st);
-    LAUNCHCHK(); PROF(K_GEMM);
+    if (!G.mel_grad_only) {
+        gemm_plain(pipe, db.xm, 128, d->melB, 128, d->melBpk, nullptr, G.gmag, kFS, b->NF, kFS, 128, st);
+        LAUNCHCHK(); PROF(K_GEMM);
+    }
     return AWARE_OK;
 }
 
@@ -1201,7 +1272,8 @@ extern "C" int aware_embed_create(aware_embed** out, const aware_plan* plan, con
                                   size_t workspace_bytes, void* stream) {
     if (!out || !plan || !det || !b || !cfg || !workspace) return AWARE_E_BADARG;
     if (cfg->num_iterations < 1 || cfg->num_iterations > 4096 || cfg->loss < 0 || cfg->loss > AWARE_LOSS_PUSH_L1) return AWARE_E_BADARG;
-    if (cfg->conv_pipe < 0 || cfg->conv_pipe > 2 || cfg->readout < 0 || cfg->readout > 1) return AWARE_E_BADARG;
+    if (cfg->conv_pipe < 0 || cfg->conv_pipe > 2 || cfg->readout < 0 || cfg->readout > 1 || cfg->mel < 0 || cfg->mel > 1)
+        return AWARE_E_BADARG;
     if (cfg->dsp_path < 0 || cfg->dsp_path > 1) return AWARE_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     aware_embed* e = new aware_embed();
@@ -1384,6 +1456,11 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
     L.sig = e->yraw; L.sig_off = b->d_out_off; L.sig_len = b->d_out_len;
     L.pmax = e->pmaxY; L.pcount = b->d_pc_syn; L.pstride = b->pstride; L.double_norm = 1;
     L.mag = e->mag; L.unit = e->U; L.unit_default = 0.f; L.write_pad = 0;
+    // the mel projection as short runs of adjacent bins inside the streaming analysis kernel (no magnitude array), and its
+    // backward as two taps per bin inside the synthesis adjoint (below): streaming DSP path and a filter bank of that form
+    const bool mel_taps = dsp == 0 && d->melw && d->melm && stream_supported(e->plan->dev) && e->cfg.mel == 0;
+    const bool mel_fold = mel_taps && d->melf_w && d->melf_s && d->n_mels == 128;
+    if (mel_fold) { L.mel_out = e->db.xm; L.melf_w = d->melf_w; L.melf_s = d->melf_s; }
     run_analysis(L, dsp, st);
     LAUNCHCHK(); PROF(K_ANALYSIS);
     // :107 detector forward, :109 loss, :120-122 best tracking, :111 backward through the detector
@@ -1395,6 +1472,8 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
     // inside the optimiser loop (multibit_embedder.py:120-122)
     G.best_loss = do_step ? e->best_loss : nullptr;
     G.improved = do_step ? e->improved : nullptr;
+    G.mel_grad_only = mel_taps;
+    G.xm_ready = mel_fold;
     int rc = det_forward_backward(d, b, e->mag, e->db, G, st);
     if (rc) return rc;
     // backward through |.|, STFT, reflect padding
@@ -1402,6 +1481,7 @@ static int embed_iteration(aware_embed* e, hipStream_t st, int do_step, float* g
     SA.plan = e->plan->dev; SA.frame_off = b->d_frame_off; SA.B = b->B; SA.max_frames = b->max_frames; SA.run_blocks = b->synth_run; SA.wg_tab = b->d_syn_wg; SA.n_wg = b->n_syn_wg;
     SA.amp = e->gmag; SA.ph = e->U; SA.out = e->gy; SA.adjoint = 1; SA.yraw = e->yraw; SA.pmax_in = e->pmaxY;
     SA.pcount = b->d_pc_syn; SA.pdot = e->pdot; SA.pstride = b->pstride; SA.gpad = e->gpad;
+    if (mel_taps) { SA.dmel = e->db.xm; SA.melw = d->melw; SA.melm = d->melm; }
     run_synth(SA, dsp, st);
     LAUNCHCHK(); PROF(K_SYNTH_ADJ);
     // backward through the normalisers, ISTFT and the assembler; :112-117 NAdam + clamp

@@ -10,6 +10,10 @@ namespace aware {
 // `nband` entries valid (bin k = band_lo + f) and the tail zero.  kFS = 256 keeps
 // every frame row 1 KiB-aligned and makes the row the K dimension of the mel GEMM.
 constexpr int kFS = 256;
+// longest support (adjacent band columns) of mel filters 0..63 / 64..127 that the analysis kernel with the mel projection
+// folded in takes (dsp_stream.hip; the card's bank: 5 and 12)
+constexpr int kMelTapsA = 6;
+constexpr int kMelTapsB = 12;
 constexpr int kFramesPerWG = 16;     // frames transformed by one 256-thread workgroup
 constexpr int kSynthBlocks = 16;     // hop blocks of output per synthesis workgroup (needs up to 19 frames: 3 halo)
 constexpr int kSynthRounds = 5;      // ... transformed in 5 rounds of 4 waves; 187 blocks of a 3 s clip = 12 workgroups,

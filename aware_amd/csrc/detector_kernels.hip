@@ -1119,9 +1119,11 @@ __device__ __forceinline__ float mel_block_sum(float v, float* red8) {
     return ((red8[0] + red8[1]) + (red8[2] + red8[3])) + ((red8[4] + red8[5]) + (red8[6] + red8[7]));
 }
 
+// amax_out: [B][64] partial maxima of |x0| per clip (entries 0..7 written: the maximum, then zeros) for gemm_h2.hip, or null
 __global__ __launch_bounds__(512) void mel_norm_clip_fwd_kernel(const float* __restrict__ xm, const int* __restrict__ frame_off,
                                                                  const int* __restrict__ pool_off, float* __restrict__ x0,
-                                                                 float* __restrict__ stats, float* __restrict__ gstat) {
+                                                                 float* __restrict__ stats, float* __restrict__ gstat,
+                                                                 float* __restrict__ amax_out) {
     __shared__ float red[4][128];
     __shared__ float red8[8];
     const int b = blockIdx.x;
@@ -1160,12 +1162,29 @@ __global__ __launch_bounds__(512) void mel_norm_clip_fwd_kernel(const float* __r
     if (threadIdx.x == 0) { gstat[b * 4 + 0] = ginv; gstat[b * 4 + 1] = gs; gstat[b * 4 + 2] = n; gstat[b * 4 + 3] = (float)T; }
     float* o = x0 + (size_t)pool_off[b] * 128 + c;
     const int Tpad = (Tp + 31) & ~31;
+    float omax = 0.f;
 #pragma unroll
     for (int i = 0; i < kMelClipR; ++i) {
         const int tp = g + 4 * i;
         const float u0 = (xa[i] - mu) * rs, u1 = (xb[i] - mu) * rs;
-        if (tp < Tp) o[(size_t)tp * 128] = 0.5f * (u0 * ginv + u1 * ginv);       // AvgPool1d(2, 2)
-        else if (tp < Tpad) o[(size_t)tp * 128] = 0.f;                            // pad rows stay finite
+        if (tp < Tp) {
+            const float v = 0.5f * (u0 * ginv + u1 * ginv);                       // AvgPool1d(2, 2)
+            o[(size_t)tp * 128] = v;
+            omax = fmaxf(omax, fabsf(v));
+        } else if (tp < Tpad) o[(size_t)tp * 128] = 0.f;                          // pad rows stay finite
+    }
+    if (amax_out) {
+#pragma unroll
+        for (int of = 32; of > 0; of >>= 1) omax = fmaxf(omax, __shfl_xor(omax, of));
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red8[threadIdx.x >> 6] = omax;
+        __syncthreads();
+        if (threadIdx.x < 8) {
+            float m = red8[0];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) m = fmaxf(m, red8[w]);
+            amax_out[(size_t)b * 64 + threadIdx.x] = threadIdx.x == 0 ? m : 0.f;
+        }
     }
 }
 
@@ -1215,16 +1234,18 @@ __global__ __launch_bounds__(512) void mel_norm_clip_bwd_kernel(const float* __r
     }
 }
 
-void launch_mel_norm_fwd(const float* xm, const int* frame_off, const int* pool_off, float* x0, float* stats,
-                         float* gstat, float* part, int pstride, int B, int max_frames, hipStream_t st) {
+// returns true when amax_out was written (single-kernel form only)
+bool launch_mel_norm_fwd(const float* xm, const int* frame_off, const int* pool_off, float* x0, float* stats,
+                         float* gstat, float* part, int pstride, int B, int max_frames, hipStream_t st, float* amax_out) {
     if (max_frames <= kMelClipFrames) {
-        hipLaunchKernelGGL(mel_norm_clip_fwd_kernel, dim3(B), dim3(512), 0, st, xm, frame_off, pool_off, x0, stats, gstat);
-        return;
+        hipLaunchKernelGGL(mel_norm_clip_fwd_kernel, dim3(B), dim3(512), 0, st, xm, frame_off, pool_off, x0, stats, gstat, amax_out);
+        return amax_out != nullptr;
     }
     const int nx = (max_frames + kMelChunk - 1) / kMelChunk;
     hipLaunchKernelGGL(mel_partial_stats_kernel, dim3(nx, B), dim3(256), 0, st, xm, frame_off, part, pstride);
     hipLaunchKernelGGL(mel_apply_pool_kernel, dim3(nx, B), dim3(256), 0, st, xm, frame_off, pool_off, part, pstride, x0, stats,
                        gstat);
+    return false;
 }
 void launch_mel_norm_bwd(const float* dx0, float* xm, const int* frame_off, const int* pool_off, const float* stats,
                          const float* gstat, float* part, int pstride, int B, int max_frames, hipStream_t st) {

@@ -140,7 +140,13 @@ struct AnalysisArgs {
     const float* c0;                  // AN_ADJ (streaming): original coefficients [NF][kFS]; the clamp's box is recomputed from
     float box_ratio;                  //   them (one operand instead of lo and hi): box_bounds(c0, box_ratio)
     float l1_weight;                  // loss push_extremes + L1 (EXTENSION): dL/dc += l1_weight * sign(c - c0) / (nband * T)
+    // streaming AN_NORM with the mel projection folded in (mag is not written): mel_out[row][m] = sum_j melf_w[m][j] *
+    // |X|[melf_s[m] + j], j < kMelTapsA (m < 64) / kMelTapsB (m >= 64): a triangular filter is a short run of adjacent bins
+    float* mel_out;                   // [NF][128]
+    const float* melf_w;              // [128][kMelTapsB], zero beyond the filter's support
+    const unsigned char* melf_s;      // [128] first band column of the support (<= kFS - kMelTapsB)
 };
+
 
 
 struct SynthArgs {
@@ -167,6 +173,12 @@ struct SynthArgs {
     // gradient goes to out + sig_off[b], sig_len[b] samples, the right reflect pad mirrors about sample n - 1
     const int* sig_off;
     const int* sig_len;
+    // streaming SY_ADJ with the mel projection's backward folded in: amp is not read; the amplitude of band column f is
+    //   melw[f].x * dmel[row][melm[f]] + melw[f].y * dmel[row][melm[f] + 1]
+    // (dmel [NF][128] = dL/d(mel); a triangular mel filter bank has at most two adjacent non-zero weights per bin)
+    const float* dmel;
+    const float2* melw;               // [kFS]
+    const unsigned char* melm;        // [kFS], <= 126
 };
 
 

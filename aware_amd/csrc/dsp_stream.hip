@@ -71,8 +71,12 @@ __device__ __forceinline__ float env_at(const PlanDev& pl, int p, int T) {
 // Analysis: a wave transforms frames t0 .. t0 + nfr - 1 of one clip
 // ---------------------------------------------------------------------------------------------------------
 // L1: the push_extremes + L1 objective (EXTENSION) adds l1_weight * sign(c - c0) / (nband T) to the gradient
-template <int MODE, bool L1>
+// MELF (AN_NORM only): the magnitudes go through the mel filter bank here -- a filter is a run of at most kMelTapsB adjacent
+// band columns, 450 non-zero weights in all for the card's bank -- and the frame's 128 mel values are written instead of its
+// 256 magnitudes (the dense K = 256 GEMM of the mel block and its operand never exist)
+template <int MODE, bool L1, bool MELF = false>
 __global__ __launch_bounds__(kSThreads, MODE == AN_ADJ ? 3 : 4) void analysis_stream_kernel(AnalysisArgs a, int run_frames) {
+    __shared__ float magrow_s[MELF ? kSW : 1][MELF ? kFS : 1];
     __shared__ cf tw1s[512];
     __shared__ cf tw2s[64];
     __shared__ float2 wins[512];
@@ -187,6 +191,17 @@ __global__ __launch_bounds__(kSThreads, MODE == AN_ADJ ? 3 : 4) void analysis_st
     }
 
     const float l1g = (MODE == AN_ADJ && L1) ? a.l1_weight / (float)(nband * T) : 0.f;
+    // MELF: this lane's two filters (mel channels lane and lane + 64): weights in registers, first column of the support
+    float wA[kMelTapsA], wB[kMelTapsB];
+    int sA = 0, sB = 0;
+    if (MELF) {
+#pragma unroll
+        for (int j = 0; j < kMelTapsA; ++j) wA[j] = a.melf_w[(size_t)lane * kMelTapsB + j];
+#pragma unroll
+        for (int j = 0; j < kMelTapsB; ++j) wB[j] = a.melf_w[(size_t)(lane + 64) * kMelTapsB + j];
+        sA = a.melf_s[lane];
+        sB = a.melf_s[lane + 64];
+    }
     float2 raw[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) raw[r] = load_half(kHop * t0 + 128 * r);
@@ -242,7 +257,8 @@ __global__ __launch_bounds__(kSThreads, MODE == AN_ADJ ? 3 : 4) void analysis_st
             if (MODE == AN_NORM) {
                 const float mg = fast_sqrt(X.x * X.x + X.y * X.y);
                 const float im = fast_rcp(mg);
-                if (a.mag) a.mag[idx] = mg;
+                if (MELF) magrow_s[wave][f] = mg;
+                else if (a.mag) a.mag[idx] = mg;
                 if (a.unit) a.unit[idx] = (mg > 0.f) ? mk(X.x * im, X.y * im) : mk(a.unit_default, 0.f);
             } else {
                 // dL/dc = Re(G conj P) with G = (2/N) rfft(.)  [adjoint of irfft on interior bins]
@@ -265,6 +281,23 @@ __global__ __launch_bounds__(kSThreads, MODE == AN_ADJ ? 3 : 4) void analysis_st
                 }
             }
         }
+        if (MODE == AN_NORM && MELF) {
+            // columns nband..255 of the wave's magnitude row are zero (written once per frame: 31 columns, lanes 1..31 of slot 4);
+            // LDS operations of one wave complete in order: no barrier between these stores and the reads below
+            float* mr = magrow_s[MELF ? wave : 0];
+            {
+                const int f = lane + 256 - band_lo;
+                if (f >= nband && f < kFS) mr[f] = 0.f;
+            }
+            float m0 = 0.f, m1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < kMelTapsA; ++j) m0 += wA[j] * mr[sA + j];
+#pragma unroll
+            for (int j = 0; j < kMelTapsB; ++j) m1 += wB[j] * mr[sB + j];
+            float* mo = a.mel_out + row * 128;
+            mo[lane] = m0;
+            mo[lane + 64] = m1;
+        }
         if (MODE == AN_NORM && a.write_pad) {
             // zero tail of the row (columns nband..255); the embed loop keeps it zero from aware_embed_create on
 #pragma unroll
@@ -284,8 +317,12 @@ __global__ __launch_bounds__(kSThreads, MODE == AN_ADJ ? 3 : 4) void analysis_st
 // Synthesis: a wave produces the hop blocks [jb0, jb1) of one clip from frames jb0-1 .. jb1+1
 // ---------------------------------------------------------------------------------------------------------
 // L1 (SY_FWD only): also emit the per-run sums of |amp - c0| for the loss value of the push_extremes + L1 objective
-template <int MODE, bool L1>
+// MELG (SY_ADJ only): the amplitudes are dL/d|S| = (dL/dmel) * melB, expanded here from the 128 mel gradients of the frame
+// through the filter bank's two taps per bin (the dense K = 128 GEMM and its [NF][256] result never exist)
+template <int MODE, bool L1, bool MELG = false>
 __global__ __launch_bounds__(kSThreads, 4) void synth_stream_kernel(SynthArgs a) {
+    __shared__ float2 melw_s[MELG ? kFS : 1];
+    __shared__ float melrow_s[MELG ? kSW : 1][MELG ? 128 : 1];
     __shared__ cf tw1s[512];
     __shared__ cf tw2s[64];
     __shared__ float2 wins[512];             // window * irfft scale, as sample pairs
@@ -300,6 +337,8 @@ __global__ __launch_bounds__(kSThreads, 4) void synth_stream_kernel(SynthArgs a)
         const cf w = a.plan.tw1024[i];                                   // (cos t, -sin t), t = 2 pi k / 1024
         mcs[i] = (i < 256) ? mk(0.5f * (1.f + w.y), 0.5f * w.x) : mk(0.5f * (1.f - w.y), -0.5f * w.x);
     }
+    if (MELG)
+        for (int i = tid; i < kFS; i += kSThreads) melw_s[i] = a.melw[i];
     __syncthreads();
 
     int b = blockIdx.y, wgx = blockIdx.x;
@@ -344,15 +383,44 @@ __global__ __launch_bounds__(kSThreads, 4) void synth_stream_kernel(SynthArgs a)
         fo[r] = (unsigned)min(max(f, 0), kFS - 1);
         if (f >= 0 && f < nband) inband |= 1u << r;
     }
+    // MELG: the first mel tap of slot r's column, four per register
+    unsigned mtap[2] = {0u, 0u};
+    float drow[2] = {0.f, 0.f};              // the frame's 128 mel gradients, two per lane (MELG)
+    if (MELG) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) mtap[r >> 2] |= (unsigned)a.melm[fo[r]] << (8 * (r & 3));
+    }
     auto load_band = [&](int t) {
         const size_t row = (size_t)(f0 + t);
-        const float* A = a.amp + row * kFS;
+        const float* A = MELG ? nullptr : a.amp + row * kFS;
         const cf* P = a.ph + row * kFS;
+        if (MELG) {
+            const float* D = a.dmel + row * 128;
+            drow[0] = D[lane];
+            drow[1] = D[lane + 64];
+        }
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            const float am = A[fo[r]];
             inP[r] = P[fo[r]];
-            inA[r] = ((inband >> r) & 1u) ? am : 0.f;
+            if (!MELG) {
+                const float am = A[fo[r]];
+                inA[r] = ((inband >> r) & 1u) ? am : 0.f;
+            }
+        }
+    };
+    // MELG: this frame's amplitudes from its mel gradients (through the wave's own 512 bytes of LDS; LDS operations of one
+    // wave complete in order, so neither a barrier nor a fence is needed)
+    auto expand_mel = [&]() {
+        float* mr = melrow_s[MELG ? wave : 0];
+        mr[lane] = drow[0];
+        mr[lane + 64] = drow[1];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const unsigned m = (mtap[r >> 2] >> (8 * (r & 3))) & 0xFFu;
+            const float2 w = melw_s[MELG ? fo[r] : 0];
+            const float v = w.x * mr[m] + w.y * mr[m + 1];
+            inA[r] = ((inband >> r) & 1u) ? v : 0.f;
+            if (r == 3) __builtin_amdgcn_sched_barrier(0);      // two rounds of four slots: 16, not 32, registers in flight
         }
     };
 
@@ -452,6 +520,7 @@ __global__ __launch_bounds__(kSThreads, 4) void synth_stream_kernel(SynthArgs a)
         epi_operands(i, emit, e0, e1);
         float2 c[8];
         {
+            if (MELG) expand_mel();
             if (MODE == SY_FWD && L1 && ((t >= jb0 && t < jb1) || (last && t == T - 1))) {
                 // own bins of the slots: k = lane + 64 r <= 256 (r < 4, and lane 0 of r = 4)
                 const float* C0 = a.c0 + (size_t)(f0 + t) * kFS;
@@ -563,7 +632,10 @@ void launch_analysis_stream(const AnalysisLaunch& L, hipStream_t st) {
     }
     if (L.adjoint && a.l1_weight != 0.f) hipLaunchKernelGGL((analysis_stream_kernel<AN_ADJ, true>), grid, dim3(kSThreads), 0, st, a, R);
     else if (L.adjoint) hipLaunchKernelGGL((analysis_stream_kernel<AN_ADJ, false>), grid, dim3(kSThreads), 0, st, a, R);
-    else hipLaunchKernelGGL((analysis_stream_kernel<AN_NORM, false>), grid, dim3(kSThreads), 0, st, a, R);
+    else if (L.mel_out && L.melf_w && L.melf_s) {
+        a.mel_out = L.mel_out; a.melf_w = L.melf_w; a.melf_s = L.melf_s; a.mag = nullptr;
+        hipLaunchKernelGGL((analysis_stream_kernel<AN_NORM, false, true>), grid, dim3(kSThreads), 0, st, a, R);
+    } else hipLaunchKernelGGL((analysis_stream_kernel<AN_NORM, false>), grid, dim3(kSThreads), 0, st, a, R);
 }
 
 void launch_synth_stream(const SynthLaunch& L, hipStream_t st) {
@@ -583,7 +655,9 @@ void launch_synth_stream(const SynthLaunch& L, hipStream_t st) {
         a.wg_tab = L.wg_tab;
         grid = dim3((unsigned)L.n_wg, 1, 1);
     }
-    if (L.adjoint) hipLaunchKernelGGL((synth_stream_kernel<SY_ADJ, false>), grid, dim3(kSThreads), 0, st, a);
+    a.dmel = L.dmel; a.melw = (const float2*)L.melw; a.melm = L.melm;
+    if (L.adjoint && L.dmel && L.melw && L.melm) hipLaunchKernelGGL((synth_stream_kernel<SY_ADJ, false, true>), grid, dim3(kSThreads), 0, st, a);
+    else if (L.adjoint) hipLaunchKernelGGL((synth_stream_kernel<SY_ADJ, false>), grid, dim3(kSThreads), 0, st, a);
     else if (a.pl1) hipLaunchKernelGGL((synth_stream_kernel<SY_FWD, true>), grid, dim3(kSThreads), 0, st, a);
     else hipLaunchKernelGGL((synth_stream_kernel<SY_FWD, false>), grid, dim3(kSThreads), 0, st, a);
 }

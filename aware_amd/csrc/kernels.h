@@ -50,6 +50,9 @@ struct AnalysisLaunch {
     const float* c0 = nullptr;        // stream + adjoint: original coefficients (the box is recomputed from them)
     float box_ratio = 0.f;            // 10^(-tolerance_db / 20)
     float l1_weight = 0.f;            // != 0: L1 term on the coefficients (loss push_extremes + L1)
+    float* mel_out = nullptr;         // stream, forward: the mel tile [NF][128] instead of mag (AnalysisArgs)
+    const float* melf_w = nullptr;
+    const unsigned char* melf_s = nullptr;
 };
 struct SynthLaunch {
     PlanDev plan;
@@ -76,6 +79,9 @@ struct SynthLaunch {
     double* pl1 = nullptr;
     const int* sig_off = nullptr;     // staged adjoint on a full spectrum: general-length output (see SynthArgs)
     const int* sig_len = nullptr;
+    const float* dmel = nullptr;      // stream + adjoint: amplitudes from dL/d(mel) [NF][128] through the two-tap table (SynthArgs)
+    const void* melw = nullptr;
+    const unsigned char* melm = nullptr;
 };
 void launch_absmax_partials(const float* sig, const int* sig_off, const int* sig_len, unsigned long long* pmax,
                             int pstride, int B, int max_len, hipStream_t st);
@@ -164,8 +170,9 @@ void launch_readout_grad_ragged_x3(const float* hin, int ci, const float* dZl, c
                                    const int* frame_off, const int* pool_off, const int* order, int B, hipStream_t st,
                                    float* amax_out = nullptr);
 // mel block: InstanceNorm over time, per-clip GlobalStandardize, AvgPool(2,2)
-void launch_mel_norm_fwd(const float* xm, const int* frame_off, const int* pool_off, float* x0, float* stats,
-                         float* gstat, float* part, int pstride, int B, int max_frames, hipStream_t st);
+bool launch_mel_norm_fwd(const float* xm, const int* frame_off, const int* pool_off, float* x0, float* stats,
+                         float* gstat, float* part, int pstride, int B, int max_frames, hipStream_t st,
+                         float* amax_out = nullptr);   // (amax_out as launch_mel_front_x3; returns whether it was written)
 void launch_mel_norm_bwd(const float* dx0, float* xm_inout, const int* frame_off, const int* pool_off, const float* stats,
                          const float* gstat, float* part, int pstride, int B, int max_frames, hipStream_t st);
 // conv block tail: InstanceNorm over time + LeakyReLU(0.2), in place; saves rstd

@@ -369,7 +369,7 @@ class EmbedSession:
 
     def __init__(self, plan: Plan, det: DetectorWeights, batch: Batch, num_iterations=400, tolerance_db=6.0,
                  loss="push_extremes", lr=0.1, beta1=0.9, beta2=0.999, eps=1e-8, momentum_decay=4e-3,
-                 use_graph=True, conv_pipe="f16x2", fused_readout=True, dsp_path="stream", l1_weight=0.0):
+                 use_graph=True, conv_pipe="f16x2", fused_readout=True, dsp_path="stream", l1_weight=0.0, mel="taps"):
         """conv_pipe: "f16x2" (default: conv blocks of chip-filling uniform batches on the f16 matrix pipe, two-term operand
         split, three products -- gemm_h2.hip; everything else as "bf16x3"), "bf16x3" (bf16 matrix pipe, exact three-way operand
         split, six products -- gemm_x3.hip) or "f32" (f32-input MFMA);
@@ -383,7 +383,8 @@ class EmbedSession:
             raise ValueError(f"Unknown conv_pipe: {conv_pipe}")
         self.cfg = EmbedConfig(int(num_iterations), float(tolerance_db), LOSS_KINDS[loss], lr, beta1, beta2, eps,
                                momentum_decay, int(bool(use_graph)), CONV_PIPES[conv_pipe],
-                               0 if fused_readout else 1, {"stream": 0, "staged": 1}[dsp_path], float(l1_weight))
+                               0 if fused_readout else 1, {"stream": 0, "staged": 1}[dsp_path], float(l1_weight),
+                               {"taps": 0, "dense": 1}[mel])
         self.nbytes = self.lib.aware_embed_workspace_bytes(batch.h, det.h)
         self.ws = torch.empty(self.nbytes, dtype=torch.uint8, device=_dev())
         h = C.c_void_p()

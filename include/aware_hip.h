@@ -224,6 +224,11 @@ typedef struct aware_embed_config {
     /* loss AWARE_LOSS_PUSH_L1 only (EXTENSION, BASELINE config 3 "BER + L1"; the reference's imperceptibility device is
      * the box constraint :157-160, which stays in force): weight of mean|c - c0| over a clip's 225*T coefficients */
     float l1_weight;
+    /* mel 0: the mel projection's backward runs as two taps per bin inside the streaming synthesis adjoint (a triangular filter
+     *   bank -- detection/modules/mel.py:105-149 -- has at most two adjacent non-zero weights per FFT bin; dL/d|S| is never
+     *   stored) whenever dsp_path is 0 and the detector's basis has that form; 1: the dense [NF][128] x [128][256] GEMM
+     *   (what the fused form is tested against). */
+    int mel;
 } aware_embed_config;
 
 /* ---- optimiser / scheduler registries (the reference's third seam: embedding/optimizers.py:3-20, schedulers.py:3-16) ------

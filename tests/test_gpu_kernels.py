@@ -453,8 +453,33 @@ def test_first_iteration_x3_vs_f32_pipe(rt, plan, det, O, nclips):
         sl = [slice(batch.frame_offsets[i], batch.frame_offsets[i + 1]) for i in range(nclips)]
         rel = np.asarray([((g4[s_] - g0[s_]).norm() / g0[s_].norm()).item() for s_ in sl])
         print(f"relative L2 difference of the gradients per clip, {pipe} vs f32 MFMA: median {np.median(rel):.2e} max {rel.max():.2e}")
-        # (a clip with a LeakyReLU argument within rounding of its kink may take the other sub-gradient: isolated, finite)
-        assert np.median(rel) < 2e-5 and int((rel > 2e-5).sum()) <= max(1, nclips // 20), rel
+        # A clip with a LeakyReLU argument within rounding of its kink may take the other sub-gradient: isolated, finite.  Expected
+        # count: 244 000 pre-activations per clip, standard normal, the pipes 2e-7 apart -> about 0.04 flips per clip, Poisson
+        # mean 1.6 at 40 clips; the bound is its 99.5 % quantile (5), not "at most two" (which fails one run in five).
+        assert np.median(rel) < 2e-5 and int((rel > 2e-5).sum()) <= max(2, nclips // 8), rel
+
+
+@pytest.mark.parametrize("lengths", [[48000] * 6, [16000, 52000, 31000, 48000], [160000, 20000]])
+def test_mel_taps_match_dense_gemm(rt, plan, det, O, lengths):
+    """The mel projection folded into the streaming DSP kernels -- forward: each of the 128 triangular filters
+    (detection/modules/mel.py:105-149) as a run of at most 12 adjacent band columns inside the analysis kernel, the magnitudes
+    never stored; backward: two taps per FFT bin inside the synthesis adjoint, dL/d|S| never stored -- against the two dense GEMMs
+    ([NF][256] x [256][128] and back; aware_embed_config.mel = 1): the same loss, prediction and first-iteration gradient to
+    f32 rounding, uniform and ragged batches, clips longer than the one-workgroup mel kernel's 192 frames."""
+    pairs = [make_clip(70 + i, n) for i, n in enumerate(lengths)]
+    wm = np.stack([O.bits_to_bipolar(p[1]) for p in pairs]).astype(np.float32)
+    batch = rt.Batch(lengths)
+    res = []
+    for mel in ("taps", "dense"):
+        sess = rt.EmbedSession(plan, det, batch, use_graph=False, mel=mel)
+        sess.begin(batch.pack([p[0] for p in pairs]), torch.from_numpy(wm).cuda())
+        g = sess.gradient().cpu().double()
+        res.append((g, sess.loss.cpu().numpy().copy(), sess.pred.cpu().numpy().copy()))
+    assert np.max(np.abs(res[0][1] - res[1][1])) < 2e-6 and np.max(np.abs(res[0][2] - res[1][2])) < 2e-6
+    for i in range(len(lengths)):
+        s_ = slice(batch.frame_offsets[i], batch.frame_offsets[i + 1])
+        rel = ((res[0][0][s_] - res[1][0][s_]).norm() / res[1][0][s_].norm()).item()
+        assert rel < 5e-6, (i, rel)
 
 
 @pytest.mark.parametrize("n", [16000, 48000, 33000, 64000])

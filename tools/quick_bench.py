@@ -12,12 +12,13 @@ n = 48000
 plan = rt.Plan()
 pipe = sys.argv[4] if len(sys.argv) > 4 and sys.argv[4] in ("f32", "bf16x3", "f16x2") else "f16x2"
 dsp = sys.argv[6] if len(sys.argv) > 6 else "stream"
+mel = os.environ.get("QB_MEL", "taps")
 det = AWAREDetectorNet().device_weights(plan)
 batch = rt.Batch([n] * B)
 g = torch.Generator(device="cuda").manual_seed(0)
 audio = 0.1 * torch.randn(B * n, device="cuda", generator=g)
 target = (torch.randint(0, 2, (B, 20), device="cuda", generator=g).float() * 2 - 1)
-sess = rt.EmbedSession(plan, det, batch, use_graph=bool(graph), conv_pipe=pipe, num_iterations=iters + 16, dsp_path=dsp)
+sess = rt.EmbedSession(plan, det, batch, use_graph=bool(graph), conv_pipe=pipe, num_iterations=iters + 16, dsp_path=dsp, mel=mel)
 sess.begin(audio, target)
 sess.iterate(5)
 torch.cuda.synchronize()
