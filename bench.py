@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: dense f32-input MFMA peak
 MFMA_BF16_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak
+MFMA_SUSTAINED_TF = 1247.0     # a tuned dense bf16 GEMM on random data (MI355X_MICROARCH.md, DVFS give-back item 1): what the pipe sustains
 WORKLOADS = ["config2", "config3", "config3_l1", "config4", "config5", "stub"]
 CONFIG5_KINDS = ["pcm", "resample", "lowpass", "bandstop", "cut", "noise"]
 
@@ -422,6 +423,10 @@ def main():
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None, "peak_note": peak_note,
                 "frac_of_f32_mfma_peak": round(achieved / MFMA_F32_PEAK_TF, 4),
                 "frac_of_six_product_peak": round(achieved / (MFMA_BF16_PEAK_TF / 6.0), 4),
+                "frac_of_sustained": round(achieved / (MFMA_SUSTAINED_TF / (3.0 if on_h2 else 6.0)), 4),
+                "frac_of_sustained_note": "achieved / (1.247 PFLOP/s / partial products): 1 247 TFLOP/s = what MI355X_MICROARCH.md (DVFS give-back, item 1) gives "
+                                          "for a tuned dense 16-bit GEMM on random data (DVFS give-back); this repo's MFMA-only variant "
+                                          "of the conv kernel measures 1.18 on finite operands (profiles/r03_gemm_planes_experiment.txt)",
                 "frac_note": "frac = achieved / (2.5 PFLOP/s / partial products per multiply-add of the kernel that ran); round 2's "
                              "bf16x3 kernel ran 6 products (peak 416.7, frac 0.45-0.47), the f16 two-term kernel runs 3 (peak 833.3): "
                              "frac_of_six_product_peak relates this run to round 2's denominator",

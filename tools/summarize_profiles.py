@@ -94,7 +94,11 @@ if abl:
         f.write("Timing-only ablations of gemm_clip_h2_kernel's K loop (results invalid; tools/build_variant.sh ... -DH2_ABL=bits,\n"
                 "tools/h2_time.py 256 94 under rocprofv3 --kernel-trace --stats): average microseconds per launch.\n"
                 "bits: 1 no split arithmetic, 2 no LDS stores, 4 no fragment reads, 8 no weight-fragment loads, 16 no barrier,\n"
-                "32 no global A loads; 63 = MFMAs + epilogue only.\n\n")
+                "32 no global A loads; 63 = MFMAs + epilogue only.\n"
+                "Read the rows as UPPER bounds of what removing a part would save: a variant without the split feeds raw f32 bit\n"
+                "patterns (NaNs among them) to the matrix pipe, one without loads keeps multiplying the same registers -- both draw\n"
+                "less power than live data and may run at a higher DVFS clock.  profiles/r03_gemm_planes_experiment.txt has the\n"
+                "same ablations on finite, changing operands (MFMAs only: 1.18 PFLOP/s issued, the chip's sustained rate).\n\n")
         for path in abl:
             v = path.split(os.sep)[-3][len("abl_"):]
             rows = [r for r in csv.DictReader(open(path)) if "gemm_clip_h2_kernel" in r["Name"]]
