@@ -1,3 +1,3 @@
-from .audio import BER, SNR, snr_batch
+from .audio import BER, SNR, STOI, snr_batch, stoi
 
-__all__ = ["BER", "SNR", "snr_batch"]
+__all__ = ["BER", "SNR", "STOI", "snr_batch", "stoi"]
