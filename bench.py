@@ -125,8 +125,8 @@ def make_attack_of_kind(kind):
 
 def cpu_baseline(workload):
     """The CPU oracle (a restatement of the reference's torch-CPU path, kind "port") timed on this host on a bounded
-    sample of the same workload: ONE 3 s clip through front end -> embed -> attack stack -> detect, with as many of
-    the 400 embed iterations as fit the budget (work per iteration is constant, so the full embed is extrapolated)."""
+    sample of the same workload: THREE 3 s clips as one batch through front end -> embed (all 400 iterations, nothing
+    extrapolated) -> attack stack -> detect: about 10 s of CPU work on the box's 16 cores."""
     import numpy as np
     import torch
     from oracle import aware_oracle as O
@@ -137,35 +137,41 @@ def cpu_baseline(workload):
     cores = max(1, min(16, avail))      # the GPU box gives one GPU's share of the host: 16 cores
     torch.set_num_threads(cores)
     rng = np.random.default_rng(0)
-    x44 = (0.1 * rng.standard_normal(132300)).astype(np.float32)
-    wm = (2 * rng.integers(0, 2, 20) - 1).astype(np.float32)
+    nclips = 3
+    x44 = (0.1 * rng.standard_normal((nclips, 132300))).astype(np.float32)
+    wm = (2 * rng.integers(0, 2, (nclips, 20)) - 1).astype(np.float32)
+    # warm-up: thread pools, allocator, filter designs (none of it is the workload)
+    w16 = np.stack([O.resample_poly(x, 160, 441) for x in x44]).astype(np.float32)
+    O.Embedder(num_iterations=5).embed(w16, wm)
+    if workload != "config2":
+        O.pcm_bit_depth(O.gaussian_noise_attack(np.asarray(O.lowpass_attack(O.resample_attack(w16[0], 16000, 16000), 16000),
+                                                           dtype=np.float32), 20.0, 0), 16)
+    t_all = time.time()
     t0 = time.time()
-    audio = O.resample_poly(x44, 160, 441).astype(np.float32)           # scripts/test.py:60-63
+    audio = np.stack([O.resample_poly(x, 160, 441) for x in x44]).astype(np.float32)     # scripts/test.py:60-63
     t_front = time.time() - t0
-    iters = 40
-    emb = O.Embedder(num_iterations=iters)
-    emb.embed(audio[None], wm[None])                       # warm-up (thread pools, allocator)
+    emb = O.Embedder(num_iterations=400)
     t0 = time.time()
-    y, _ = emb.embed(audio[None], wm[None])
+    y, _ = emb.embed(audio, wm)
     t_emb = time.time() - t0
-    y = y[0].numpy()
+    ys = [y[i].numpy() for i in range(nclips)]
     t_att = 0.0
     if workload != "config2":
         t0 = time.time()
-        y = O.resample_attack(y, 16000, 16000)
-        y = O.lowpass_attack(y, 16000)
-        y = O.gaussian_noise_attack(np.asarray(y, dtype=np.float32), 20.0, 0)
-        y = O.pcm_bit_depth(y, 16)
+        for i in range(nclips):
+            v = O.resample_attack(ys[i], 16000, 16000)
+            v = O.lowpass_attack(v, 16000)
+            v = O.gaussian_noise_attack(np.asarray(v, dtype=np.float32), 20.0, i)
+            ys[i] = O.pcm_bit_depth(v, 16)
         t_att = time.time() - t0
     t0 = time.time()
-    emb.detect_raw(np.asarray(y, dtype=np.float32)[None])
+    emb.detect_raw(np.stack([np.asarray(v, dtype=np.float32) for v in ys]))
     t_det = time.time() - t0
-    per_iter = t_emb / iters
-    full = t_front + per_iter * 400 + t_att + t_det
-    return {"value": 3.0 / full, "unit": "waveform-seconds/sec", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": f"1 x 3 s clip: front end {t_front*1e3:.0f} ms + {iters} of 400 embed iterations timed "
-                      f"({per_iter*1e3:.1f} ms/iter, extrapolated x400) + attack stack {t_att*1e3:.0f} ms + 1 detect "
-                      f"({t_det*1e3:.1f} ms); vectorised bounds (no 1.3 s/clip Python loop)"}
+    full = time.time() - t_all
+    return {"value": 3.0 * nclips / full, "unit": "waveform-seconds/sec", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"{nclips} x 3 s clips as one batch, everything timed ({full:.1f} s): front end {t_front*1e3:.0f} ms + 400 embed "
+                      f"iterations {t_emb:.2f} s ({t_emb / 400 * 1e3:.1f} ms/iter for the batch) + attack stack {t_att*1e3:.0f} ms + "
+                      f"detect {t_det*1e3:.1f} ms; vectorised bounds (no 1.3 s/clip Python loop)"}
 
 
 def kernel_source_hash():
