@@ -201,6 +201,12 @@ __global__ __launch_bounds__(kSThreads, MODE == AN_ADJ ? 3 : 4) void analysis_st
         for (int j = 0; j < kMelTapsB; ++j) wB[j] = a.melf_w[(size_t)(lane + 64) * kMelTapsB + j];
         sA = a.melf_s[lane];
         sB = a.melf_s[lane + 64];
+        // the tail of the wave's magnitude row (columns nband .. kFS - 1, whatever the band) stays zero for the whole run
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int f = lane + 64 * r - band_lo;
+            if (f >= nband && f < kFS) magrow_s[MELF ? wave : 0][f] = 0.f;
+        }
     }
     float2 raw[8];
 #pragma unroll
@@ -282,13 +288,9 @@ __global__ __launch_bounds__(kSThreads, MODE == AN_ADJ ? 3 : 4) void analysis_st
             }
         }
         if (MODE == AN_NORM && MELF) {
-            // columns nband..255 of the wave's magnitude row are zero (written once per frame: 31 columns, lanes 1..31 of slot 4);
-            // LDS operations of one wave complete in order: no barrier between these stores and the reads below
+            // (columns nband..255 of the wave's magnitude row were zeroed ahead of the loop; LDS operations of one wave complete
+            //  in order: no barrier between the stores above and the reads below)
             float* mr = magrow_s[MELF ? wave : 0];
-            {
-                const int f = lane + 256 - band_lo;
-                if (f >= nband && f < kFS) mr[f] = 0.f;
-            }
             float m0 = 0.f, m1 = 0.f;
 #pragma unroll
             for (int j = 0; j < kMelTapsA; ++j) m0 += wA[j] * mr[sA + j];

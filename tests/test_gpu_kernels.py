@@ -482,6 +482,29 @@ def test_mel_taps_match_dense_gemm(rt, plan, det, O, lengths):
         assert rel < 5e-6, (i, rel)
 
 
+def test_mel_taps_other_band(rt, O):
+    """The same comparison on a band that ends below bin 256 (bins 48..180: the magnitude row's zero tail starts in the middle,
+    other filters are cut by the band edges) -- the tap tables are derived from whatever basis and band the detector gets."""
+    from aware_amd.detection import AWAREDetectorNet
+    plan2 = rt.Plan(band_bins=(48, 180))
+    det2 = AWAREDetectorNet().device_weights(plan2)
+    lengths = [48000, 30000, 48000]
+    pairs = [make_clip(90 + i, n) for i, n in enumerate(lengths)]
+    wm = np.stack([O.bits_to_bipolar(p[1]) for p in pairs]).astype(np.float32)
+    batch = rt.Batch(lengths)
+    res = []
+    for mel in ("taps", "dense"):
+        sess = rt.EmbedSession(plan2, det2, batch, use_graph=False, mel=mel)
+        sess.begin(batch.pack([p[0] for p in pairs]), torch.from_numpy(wm).cuda())
+        g = sess.gradient().cpu().double()
+        res.append((g, sess.loss.cpu().numpy().copy(), sess.pred.cpu().numpy().copy()))
+    assert np.isfinite(res[0][1]).all() and np.max(np.abs(res[0][1] - res[1][1])) < 2e-6
+    assert np.max(np.abs(res[0][2] - res[1][2])) < 2e-6
+    for i in range(len(lengths)):
+        s_ = slice(batch.frame_offsets[i], batch.frame_offsets[i + 1])
+        assert ((res[0][0][s_] - res[1][0][s_]).norm() / res[1][0][s_].norm()).item() < 5e-6
+
+
 @pytest.mark.parametrize("n", [16000, 48000, 33000, 64000])
 def test_fused_readout_vs_three_kernel_path(rt, plan, det, O, n):
     """Uniform batches run the last conv block, BRH, loss, their backward and the last data gradient in
