@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: dense f32-input MFMA peak
 MFMA_BF16_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak
 MFMA_SUSTAINED_TF = 1247.0     # a tuned dense bf16 GEMM on random data (MI355X_MICROARCH.md, DVFS give-back item 1): what the pipe sustains
-WORKLOADS = ["config2", "config3", "config3_l1", "config4", "config5", "stub"]
+WORKLOADS = ["config2", "config3", "config3_l1", "config4", "config5", "train", "stub"]
 CONFIG5_KINDS = ["pcm", "resample", "lowpass", "bandstop", "cut", "noise"]
 
 
@@ -223,26 +223,6 @@ def run_stub(args, rank, world):
     parallel.barrier()
     wall = time.perf_counter() - t0
     sums, maxes = parallel.reduce_metrics({"seconds": 3.0 * args.steps, "ranks": 1}, {"wall": wall}, device="cpu")
-    # ---- the same workload on the EXACT pipe (three bf16 terms, six products), one step on rank 0 at N = 1: the rate a reader
-    # who does not accept the two-term split as f32 arithmetic should take ----
-    exact = None
-    if world == 1 and args.conv_pipe == "f16x2" and not args.no_profile:
-        embedder.conv_pipe = "bf16x3"
-        pipe2 = WatermarkPipeline(embedder, detector, pipe.attacks, sample_rate=16000, attack_mode=pipe.attack_mode)
-        pipe2.prepare(n16, input_rate=44100)
-        pipe2.run(audio, bits, **run_kw)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        r2 = pipe2.run(audio, bits, **run_kw)
-        e2 = int(r2.bit_errors)
-        torch.cuda.synchronize()
-        w2 = time.perf_counter() - t0
-        exact = {"conv_pipe": "bf16x3", "value": round(r2.seconds / w2, 2), "unit": "waveform-seconds/sec", "steps": 1,
-                 "ms_per_step": round(w2 * 1e3, 2), "ber_percent": round(100.0 * e2 / (len(n16) * 20), 4),
-                 "note": "same workload, conv blocks on gemm_x3.hip (every f32 operand split exactly into three bf16 terms, six "
-                         "partial products, f32 accumulation): bit-level f32 operands"}
-        embedder.conv_pipe = args.conv_pipe
-        del pipe2
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
@@ -250,6 +230,57 @@ def run_stub(args, rank, world):
         print(json.dumps({"metric": "stub", "value": sums["seconds"] / maxes["wall"], "unit": "waveform-seconds/sec",
                           "n_gpus": world, "ranks_seen": int(sums["ranks"]), "steps": args.steps, "warmup": args.warmup,
                           "config": {"workload": "stub"}}))
+    return 0
+
+
+def run_train(args, rank, world):
+    """EXTENSION workload (BASELINE north_star: "RCCL all-reduce over xGMI on the embedder/detector gradients"; the reference trains
+    nothing, so there is no reference number and no parity to pin): detector training steps on this rank's clips --
+    STFT magnitudes, forward + backward INCLUDING the parameter gradients, one all-reduce of the 6.7 MB gradient bucket across
+    the ranks (RCCL; the only data-path collective in the repository), Adam on the device, device images of the weights rebuilt."""
+    import torch
+    from aware_amd import parallel
+    from aware_amd._lib import require_gpu
+    require_gpu()
+    from aware_amd import runtime as rt
+    from aware_amd.utils.models import load
+    from aware_amd.training import DetectorTrainer
+    dev = torch.device("cuda", torch.cuda.current_device())
+    per_gpu = args.clips_per_gpu or 256
+    n = int(round(args.seconds * 16000))
+    g = torch.Generator(device=dev).manual_seed(100 + rank)
+    audio = rt.Ragged(0.1 * torch.randn(per_gpu * n, device=dev, generator=g), [n] * per_gpu)
+    bits = torch.randint(0, 2, (per_gpu, 20), device=dev, generator=g)
+    _, detector = load()
+    tr = DetectorTrainer(detector, lr=1e-4)
+    for _ in range(args.warmup):
+        loss, _ = tr.step(audio, bits)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = tr.step(audio, bits)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    sums, maxes = parallel.reduce_metrics({"seconds": args.steps * per_gpu * args.seconds}, {"wall": wall}, device=dev)
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        parallel.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "waveform-seconds/sec through one detector training step (EXTENSION; not BASELINE's metric)",
+            "value": round(sums["seconds"] / maxes["wall"], 1), "unit": "waveform-seconds/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(maxes["wall"] / args.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32 (f32-input MFMA pipe: the parameter gradients are tested against autograd)",
+            "data": "synthetic",
+            "config": {"workload": f"train: {per_gpu} x {args.seconds:.0f} s clips/GPU @16 kHz, STFT band -> detector forward + backward with "
+                                   "weight gradients -> all-reduce (1.68 M parameters) -> Adam -> weight images rebuilt",
+                       "clips_per_gpu": per_gpu, "parallelism": f"dp{world} (gradient all-reduce, RCCL)"},
+            "loss": round(float(loss), 6), "roofline": None}))
     return 0
 
 
@@ -293,6 +324,8 @@ def main():
         sys.exit(2)
     if args.workload == "stub":
         sys.exit(run_stub(args, rank, world))
+    if args.workload == "train":
+        sys.exit(run_train(args, rank, world))
 
     import numpy as np
     import torch

@@ -44,3 +44,12 @@ def test_torchrun_environment_is_respected():
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     assert json.loads(lines[0])["ranks_seen"] == 2
+
+
+def test_single_rank_stub_line():
+    """--gpus 1 (the driver's default call) with no launcher environment: no spawn, one JSON line."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "0", "--workload", "stub"],
+                       env=_env(), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 1
