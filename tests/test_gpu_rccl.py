@@ -65,3 +65,44 @@ def test_bench_under_torchrun_with_rccl():
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["ber_percent_clean"] == 0.0
+
+
+def test_default_bench_line_carries_the_contract_objects():
+    """`python bench.py` (here with 32 clips per GPU and one step): ONE JSON line with the contract's keys, a `roofline`
+    object for the dominant kernel timed live (the f16 two-term conv kernel from 32 clips on), a `cpu_baseline` object from the
+    oracle on a bounded sample, and the `exact_pipe` leg."""
+    env = {k: v for k, v in _env(0).items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                         "AWARE_FORCE_COLLECTIVES")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--clips-per-gpu", "32"],
+                       env=env, capture_output=True, text=True, timeout=1200)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in out, key
+    assert out["unit"] == "waveform-seconds/sec" and out["scaling"] == "weak" and out["vs_baseline"] is None
+    assert out["steps"] == 1 and out["n_gpus"] == 1 and out["value"] > 0 and out["ber_percent_clean"] == 0.0
+    assert abs(out["value"] - 32 * 3.0 / (out["ms_per_step"] * 1e-3)) < 0.01 * out["value"]
+    r = out["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and "gemm_clip_h2_kernel" in r["kernel"]
+    assert 0 < r["achieved"] < r["peak"] and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and abs(r["peak"] - 2500 / 3) < 0.1
+    assert r["traffic"] is None or r["traffic"] > 0                 # null unless a stored counter profile matches batch and sources
+    assert r["dsp_hbm"]["bound"] == "hbm" and 0 < r["dsp_hbm"]["frac"] < 1
+    c = out["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and 0 < c["value"] < out["value"] and "clips" in c["sample"]
+    e = out["exact_pipe"]
+    assert e["conv_pipe"] == "bf16x3" and 0 < e["value"] <= 1.2 * out["value"] and e["ber_percent"] == 0.0
+
+
+def test_training_workload_with_rccl_all_reduce():
+    """`bench.py --workload train` under torch.distributed.run with one rank and the collectives forced on: the gradient bucket's
+    all-reduce and the metric reductions run on RCCL inside the timed region."""
+    env = {k: v for k, v in _env(0).items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                        "127.0.0.1", "--master-port", "29673", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "train",
+                        "--steps", "2", "--warmup", "1", "--clips-per-gpu", "16"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and 0 < out["loss"] < 10
