@@ -103,4 +103,25 @@ if abl:
             v = path.split(os.sep)[-3][len("abl_"):]
             rows = [r for r in csv.DictReader(open(path)) if "gemm_clip_h2_kernel" in r["Name"]]
             f.write(f"{v:24s} " + "  ".join(f'{r["Name"].split("<")[1].split(">")[0]}: {float(r["AverageNs"]) / 1e3:7.1f} us x{r["Calls"]}' for r in rows) + "\n")
+# clock the chip holds inside each kernel of the loop: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / dispatch duration
+mf = glob.glob(os.path.join(raw, "pmc_mfma", "*", "*counter_collection.csv"))
+if mf:
+    import collections
+    import statistics
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(mf[0])):
+        if r["Counter_Name"] != "GRBM_GUI_ACTIVE" or "aware::" not in r["Kernel_Name"]:
+            continue
+        dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        if dur > 0:
+            acc[(r["Kernel_Name"], r["Grid_Size"])].append((float(r["Counter_Value"]) / 8.0 / dur, dur))
+    with open(os.path.join(prof, f"{tag}_kernel_clocks.csv"), "w") as f:
+        f.write("# effective clock per kernel of the embed loop = GRBM_GUI_ACTIVE / 8 XCDs / dispatch duration (rocprofv3 --pmc\n"
+                "# SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace, tools/quick_bench.py " + str(B) + " 12 0; medians over the loop's launches).\n"
+                "# MI355X_MICROARCH.md, DVFS give-back: the quotient reads high on dispatches shorter than about 0.3 ms -- compare kernels of\n"
+                "# similar length: the conv GEMMs hold 1.8-1.9 GHz, the HBM-bound DSP kernels of the same length 2.4-2.5 GHz.\n"
+                "kernel,grid_threads,median_us,effective_GHz,launches\n")
+        rows_ = [(statistics.median(x[1] for x in v), k, statistics.median(x[0] for x in v), len(v)) for k, v in acc.items() if len(v) >= 8]
+        for dur, k, clk, n in sorted(rows_, reverse=True):
+            f.write(f'"{k[0][:100]}",{k[1]},{dur / 1e3:.1f},{clk:.2f},{n}\n')
 print("profiles written for", tag)
