@@ -1,3 +1,3 @@
-from .audio import BER, SNR, STOI, snr_batch, stoi
+from .audio import BER, PESQ, SNR, STOI, snr_batch, stoi
 
-__all__ = ["BER", "SNR", "STOI", "snr_batch", "stoi"]
+__all__ = ["BER", "PESQ", "SNR", "STOI", "snr_batch", "stoi"]

@@ -62,3 +62,13 @@ def test_stoi_metric_follows_the_reference_wrapper():
     y44 = x44 + 0.3 * rng.standard_normal(len(x44))
     assert 0.3 < m(y44, x44, 44100) < 1.0
     assert BER()(np.array([0, 1, 1, 0]), np.array([0, 1, 0, 0])) == 25.0 and SNR()(x, x) == float("inf")
+
+
+def test_pesq_name_exists_and_says_what_is_missing():
+    from aware_amd.metrics import PESQ
+    x, _ = _speechlike(seconds=1.0)
+    try:
+        import pesq  # noqa: F401
+    except ImportError:
+        with pytest.raises(NotImplementedError, match="P.862"):
+            PESQ()(x, x, 16000)
